@@ -1,0 +1,260 @@
+"""Parity cases shared by oracle/gen_golden.py (reference side) and tests/ (oracle and HIP side).
+
+TEST INFRASTRUCTURE ONLY.  Each case fixes seeded inputs and says how the ORACLE computes the outputs from a
+recipe state dict.  The reference-side twin of every case lives in gen_golden.py; the fixture written there
+(tests/golden/<name>.npz) holds the state-dict shapes the reference module reported and a strided subsample
+of the reference outputs plus float64 checksums.
+"""
+from __future__ import annotations
+
+import json
+from typing import Callable, Dict, List
+
+import numpy as np
+import torch
+
+from . import recipe as R
+from . import vmg_oracle as O
+
+SUBSAMPLE = 8192  # values kept per output tensor
+
+
+def subsample(t: torch.Tensor) -> np.ndarray:
+    f = t.detach().reshape(-1).to(torch.float32)
+    step = max(1, f.numel() // SUBSAMPLE)
+    return f[::step].numpy().copy()
+
+
+def checksums(t: torch.Tensor):
+    d = t.detach().double()
+    return float(d.sum()), float(d.abs().sum())
+
+
+# ---- configs used by the whole-model cases -------------------------------------------------------
+def cfg_tiny_few(T=3, temporal_empty=True, is_train=False):
+    return O.VMGConfig(embed_dim=(16, 16, 16), depths=(1, 1, 1), num_heads=(4, 4, 4), num_frames=T,
+                       window_sizes=((2, 8, 8), (2, 8, 8), (2, 8, 8)), mlp_ratio=2, n_groups=1, image_size=(64, 64),
+                       is_train=is_train, traj_win=(16, None), traj_keyframes_n=(2, None), traj_heads=(4, None),
+                       temporal_type=(False, None), temporal_empty=temporal_empty, traj_res_n=(1, 0, 1),
+                       chunk_ratios=("1/8", "1/4"), r_scaling=0.1)
+
+
+def cfg_tiny_multi(T=3):
+    return O.VMGConfig(embed_dim=(16, 32, 32, 64, 32, 32, 16), depths=(1,) * 7, num_heads=(2, 4, 4, 8, 4, 4, 2),
+                       num_frames=T, window_sizes=((2, 8, 8),) * 7, mlp_ratio=2, n_groups=4, image_size=(64, 64),
+                       is_train=False, traj_win=(16, None, None, None), traj_keyframes_n=(3, None, None, None),
+                       traj_heads=(4, None, None, None), temporal_type=(False, None, None, None), temporal_empty=True,
+                       traj_res_n=(1, 0, 0, 0, 0, 0, 1), spatial_type=(False,) * 4, mdsc=True,
+                       chunk_ratios=("1/4", "1/4", "3/16", "1/8"), r_scaling=0.1)
+
+
+def cfg_reds_few(T=5):
+    """network block of configs/VMG-REDS-few_levels.yml with num_frames = T."""
+    return O.VMGConfig(num_frames=T)
+
+
+# ---- input builders --------------------------------------------------------------------------------
+def int_locations(n, t, h, w, seed):
+    """Integer-valued tracked locations incl. a few out-of-range ones (as nearest/border warps of a pixel grid
+    produce, plus stress values)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(-2, w + 2, (n, t, 1, h, w), generator=g).float()
+    y = torch.randint(-2, h + 2, (n, t, 1, h, w), generator=g).float()
+    return torch.cat([x, y], 2).reshape(n, 2 * t, h, w)
+
+
+CASES: Dict[str, dict] = {}
+
+
+def case(name):
+    def deco(fn):
+        CASES[name] = fn()
+        CASES[name]["name"] = name
+        return fn
+    return deco
+
+
+@case("morphfc_c144_chunk8")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 24, 20, 144), 11)}
+
+    def run(sd, inp):
+        outs = [O.morphfc_decay(sd, "", inp["x"], 8, 8) for _ in range(3)]  # calls #1..#3 (T1)
+        return outs
+    return dict(inputs=inputs, run=run, chunk_of=lambda k: 8)
+
+
+@case("morphfc_c224_chunk12")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 1, 16, 16, 224), 12)}
+
+    def run(sd, inp):
+        return [O.morphfc_decay(sd, "", inp["x"], 12, 12)]
+    return dict(inputs=inputs, run=run, chunk_of=lambda k: 12)
+
+
+@case("rcab_c144")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 16, 16, 144), 13)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.rcab(sd, "", inp["x"])])
+
+
+@case("mlp_cnn_c144")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 16, 16, 144), 14)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.mlp_cnn(sd, "", inp["x"], 1)])
+
+
+@case("mlp_cnn_c112_g4")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 1, 16, 16, 112), 15)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.mlp_cnn(sd, "", inp["x"], 4)])
+
+
+@case("tab_c144")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 32, 32, 144), 16)}
+
+    def run(sd, inp):
+        cfg = O.VMGConfig()
+        return [O.tab(sd, "", inp["x"], cfg, 8, 8), O.tab(sd, "", inp["x"], cfg, 8, 8)]
+    return dict(inputs=inputs, run=run, chunk_of=lambda k: 8)
+
+
+@case("updown_down")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 16, 16, 144), 17)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.updown(sd, "", inp["x"], "down")])
+
+
+@case("updown_up")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 8, 8, 144), 18)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.updown(sd, "", inp["x"], "up")])
+
+
+@case("flow_smoothing")
+def _():
+    def inputs():
+        return {"flow": R.seeded((2, 3, 2, 30, 26), 19, 2.0)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.flow_smoothing(inp["flow"], 4)], no_weights=True)
+
+
+@case("ltam_wins")
+def _():
+    def inputs():
+        n, t, h, w, c = 2, 2, 16, 16, 144
+        return {"q": R.seeded((n, h, w, c), 20), "keys": R.seeded((n, t, h, w, c), 21), "anchor": R.seeded((n, h, w, c), 22),
+                "vals": R.seeded((n, t, h, w, c), 23), "loc": int_locations(n, t, h, w, 24)}
+
+    def run(sd, inp):
+        return [O.ltam_wins(sd, "", inp["q"], inp["keys"], inp["anchor"], inp["vals"], inp["loc"], 4, (2, 2))]
+    return dict(inputs=inputs, run=run)
+
+
+@case("trajectory_c32")
+def _():
+    def inputs():
+        return {"x": R.seeded((2, 5, 16, 16, 32), 25), "ff": R.seeded((2, 4, 2, 16, 16), 26, 1.5),
+                "fb": R.seeded((2, 4, 2, 16, 16), 27, 1.5)}
+
+    def run(sd, inp):
+        cfg = O.VMGConfig(traj_keyframes_n=(2, None), traj_heads=(4, None), r_scaling=0.1)
+        return [O.trajectory(sd, "", inp["x"], inp["ff"], inp["fb"], cfg, 0, 2)]
+    return dict(inputs=inputs, run=run)
+
+
+@case("spynet")
+def _():
+    def inputs():
+        clip = R.synthetic_clip(1, 3, 64, 64, 28)
+        return {"ref": clip[0, 1:], "supp": clip[0, :-1]}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.spynet_forward(sd, "spynet.", inp["ref"], inp["supp"])])
+
+
+@case("spynet_48x40")
+def _():
+    def inputs():
+        clip = R.synthetic_clip(1, 2, 48, 40, 29)
+        return {"ref": clip[0, 1:], "supp": clip[0, :-1]}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.spynet_forward(sd, "spynet.", inp["ref"], inp["supp"])])
+
+
+@case("sr_head")
+def _():
+    def inputs():
+        return {"y": R.seeded((2, 16, 16, 144), 30)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.sr_head(sd, inp["y"])])
+
+
+@case("swin_w2_t5")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 5, 20, 20, 32), 31)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.swin_decoder_layer(sd, "", inp["x"], 4, (2, 8, 8))],
+                window_of=lambda k: (2, 8, 8))
+
+
+@case("swin_w4_t7")
+def _():
+    def inputs():
+        return {"x": R.seeded((2, 7, 16, 16, 32), 32)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.swin_decoder_layer(sd, "", inp["x"], 8, (4, 8, 8))],
+                window_of=lambda k: (4, 8, 8))
+
+
+@case("loss")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 2, 3, 32, 32), 33, 0.3), "y": R.seeded((1, 2, 3, 32, 32), 34, 0.3)}
+    return dict(inputs=inputs, run=lambda sd, inp: [O.charbonnier_edge_loss(inp["x"], inp["y"]).reshape(1)], no_weights=True)
+
+
+def _vmg_case(cfg_fn, T, seed, calls=1):
+    def make():
+        cfg = cfg_fn(T)
+        chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+
+        def inputs():
+            return {"x": R.synthetic_clip(1, T, 64, 64, seed)}
+
+        def run(sd, inp):
+            return [O.vmg_forward(sd, cfg, inp["x"]) for _ in range(calls)]
+        return dict(inputs=inputs, run=run, chunk_of=chunk_of, window_of=window_of, cfg=cfg)
+    return make
+
+
+case("vmg_tiny_few")(_vmg_case(cfg_tiny_few, 3, 40, calls=2))
+case("vmg_tiny_multi")(_vmg_case(cfg_tiny_multi, 3, 41))
+case("vmg_tiny_swin")(_vmg_case(lambda T: cfg_tiny_few(T, temporal_empty=False), 4, 42))
+case("vmg_reds_few_cfg1")(_vmg_case(cfg_reds_few, 5, 43))
+
+
+# ---- fixture I/O -------------------------------------------------------------------------------------
+def save_fixture(path: str, shapes: Dict[str, List[int]], outs: List[torch.Tensor]):
+    arrs = {"shapes": np.frombuffer(json.dumps(shapes).encode(), dtype=np.uint8)}
+    for i, o in enumerate(outs):
+        arrs[f"out{i}"] = subsample(o)
+        arrs[f"sum{i}"] = np.array(checksums(o), dtype=np.float64)
+        arrs[f"shape{i}"] = np.array(o.shape, dtype=np.int64)
+    np.savez_compressed(path, **arrs)
+
+
+def load_fixture(path: str):
+    z = np.load(path)
+    shapes = json.loads(bytes(z["shapes"]).decode())
+    n = len([k for k in z.files if k.startswith("out")])
+    outs = [dict(sub=z[f"out{i}"], sums=z[f"sum{i}"], shape=tuple(z[f"shape{i}"])) for i in range(n)]
+    return shapes, outs
+
+
+def case_state_dict(c: dict, shapes: Dict[str, List[int]], seed: int = 0):
+    return R.recipe_state_dict(shapes, seed, chunk_of=c.get("chunk_of"), window_of=c.get("window_of"))
