@@ -1,0 +1,117 @@
+/*
+ * vmg_hip.h -- C-ABI of libvmg_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the VMG
+ * per-frame forward/backward hot path.
+ *
+ * The reference (EasyVision-Ton/VMG @ 2024_10_08) has no native code: every op below replaces a torch-op
+ * call site of the reference's Python modules (file:line cited per entry, relative to the reference root).
+ * The host side (the vmg_amd python package, an nn.Module mirror of models/vmg.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub.
+ *
+ * Conventions
+ *   - every entry returns 0 on success, <0 on error; vmg_last_error() gives the text (thread-local).
+ *   - all tensor arguments are raw DEVICE pointers; features are channels-last: (N, H, W, C), C fastest.
+ *   - `dtype`: VMG_F32 (0) or VMG_BF16 (1) = storage type of activations and packed weights; accumulation,
+ *     bias, statistics and gradients of parameters are always fp32.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised; no allocation
+ *     happens inside (packed weights / workspaces are caller-provided), so calls are hipGraph-capturable.
+ *   - strides named *_ps are PIXEL strides in elements (>= channel count), which lets a call read or write a
+ *     channel slice of a wider tensor (virtual concat / split without copies).
+ */
+#ifndef VMG_HIP_H
+#define VMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMG_F32 0
+#define VMG_BF16 1
+
+/* activation codes of the conv / linear epilogue */
+#define VMG_ACT_NONE 0
+#define VMG_ACT_RELU 1
+#define VMG_ACT_LRELU 2 /* slope argument */
+#define VMG_ACT_GELU 3  /* erf form, torch nn.GELU() default */
+
+const char* vmg_last_error(void);
+int vmg_version(void);
+/* number of bytes of dynamic LDS the largest kernel instance requests (diagnostics) */
+int vmg_max_lds_bytes(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing for the implicit-GEMM convolution.
+ *
+ * w      : fp32 weights in checkpoint layout OIHW (O, I, KS, KS); nn.Linear (O, I) is KS = 1.
+ * Forward packing (transpose_flip = 0): output channels = O[o0 : o0+on); the K dimension is the list of
+ *   `nsrc` input-channel slices [src_off[s], src_off[s]+src_ch[s]) of I, in that order, each slice a
+ *   multiple of 8 channels (one slice per tensor of a virtual channel concat).
+ * Data-gradient packing (transpose_flip = 1): output channels = I[o0 : o0+on), K = O[src_off[0] : +src_ch[0])
+ *   with taps mirrored -- conv(dY, pack) is then dX of the forward conv (stride 1, pad KS/2).
+ * The packed image is [cout_block][chunk q][co in block][8] elements of `dtype`; its size in bytes is
+ * returned by vmg_conv_pack_bytes.  `cout_tiles` (1, 4, 7, 8 or 9) is the number of 16-channel tiles per block and
+ * must be the value later passed to vmg_conv_fwd.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles);
+int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                  const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vmg_conv_fwd -- stride-1 "same" convolution (KS = 3 or 1) as MFMA implicit GEMM with fused epilogue.
+ *
+ * Replaces: nn.Conv2d 3x3 call sites models/trajectory.py:32,185-186 (recurrent residual chains),
+ *   models/function.py:567 (RCAB), :57 (Mlp_cnn.fc1), :1314 (local_cnn), models/vmg.py:378-382 (head),
+ *   and with KS = 1 every nn.Linear / 1x1 conv on the path (function.py:64,631-636,647; trajectory.py:271,517;
+ *   layers.py:769; swin_3d.py:143-149).  With a data-gradient pack it is also the backward-data pass.
+ *
+ *   v   = sum_s conv(src[s]) + bias                       (fp32 accumulate)
+ *   pre = v                                              -> out_pre if non-null
+ *   v   = act(v) * alpha
+ *   v  *= act'(aux)   if actgrad != 0  (1: aux > 0 ? 1 : 0; 2: aux > 0 ? 1 : slope; 3: gelu'(aux))
+ *   v  += res         if res != null
+ *   out = v           (pixel_shuffle = 1: stored to (N, 2H, 2W, Cout/4) in torch PixelShuffle(2) order)
+ *
+ * For KS = 1 the tensor is treated as (M = N*H*W, C) rows; H, W are only used for pixel_shuffle.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vmg_conv_desc {
+  int dtype, ks, cout_tiles; /* cout_tiles as used for packing */
+  int N, H, W, Cout;
+  int nsrc;
+  const void* src[4];
+  int64_t src_ps[4];
+  int src_ch[4];
+  const void* packed;
+  const float* bias; /* may be null */
+  void* out;
+  int64_t out_ps;
+  void* out_pre; /* may be null; same layout as out */
+  const void* res;
+  int64_t res_ps; /* may be null */
+  const void* aux;
+  int64_t aux_ps; /* may be null */
+  int act;
+  float slope, alpha;
+  int actgrad;
+  int pixel_shuffle;
+  int mt; /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
+} vmg_conv_desc;
+
+int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vmg_conv_wgrad -- weight (and bias) gradient of the same convolution, accumulated into fp32 OIHW.
+ *   dW[o][i][ky][kx] += scale * sum_{n,y,x} dY[n,y,x,o] * X[n,y+ky-KS/2,x+kx-KS/2,i]
+ *   db[o]            += scale * sum dY[n,y,x,o]                      (if db != null)
+ * dW addresses the (O_total, I_total, KS, KS) gradient of the full parameter; the call covers output channels
+ * [o0, o0+Cout) and input channels [i0, i0+Cin).  fp32 atomics: call-to-call results are summed in
+ * arrival order (see DESIGN.md "determinism").
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_t x_ps, int Cin, const void* dy,
+                   int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMG_HIP_H */

@@ -1,0 +1,497 @@
+// Stride-1 "same" convolution (KS = 3 or 1; KS = 1 is every Linear on the path) as an MFMA implicit GEMM
+// for gfx950, channels-last activations, with a fused epilogue.  See include/vmg_hip.h for the contract.
+//
+// Decomposition (one workgroup = 4 waves = 256 threads):
+//   * spatial tile of TH = 4*MT rows x 16 columns (KS = 3) or 64*MT consecutive rows of the (M, C) matrix
+//     (KS = 1); wave w owns MT 16-pixel rows of it; blockIdx.y selects a block of NTB*16 output channels.
+//   * K order = for each source tensor (a channel block of <= 160 channels; virtual concat = several sources):
+//       for tap (ky,kx): for 8-channel chunk c8.   One k-step = 4 chunks = 32 K values (one chunk per 16-lane
+//       group of the MFMA operand).  Each source's chunk count is padded to a multiple of 4 with zero weights.
+//   * the source's halo tile ((TH+2) x 18 pixels, all channels of the block) is staged once in LDS; the
+//     activation operand of every (tap, chunk) is a plain 16-byte LDS read at (pixel + tap offset).
+//   * packed weights stream through a 2-deep LDS ring, 2 k-steps per stage, with global_load_lds (16 B/lane).
+//   * MFMA: D[cout 16][pixel 16] += W[cout][k] * X[k][pixel]  (v_mfma_f32_16x16x32_bf16, or 8 x
+//     v_mfma_f32_16x16x4_f32 per k-step for fp32), so a lane ends with 4 consecutive output channels of one
+//     pixel -> 8-byte (bf16) / 16-byte (fp32) channels-last stores.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_ISRC = 32;  // internal sources after channel-block splitting
+constexpr int KSTG = 2;       // k-steps per weight stage
+constexpr int CBMAX = 160;    // max channels per internal source block
+
+struct ConvK {
+  const char* src[MAX_ISRC];
+  long long src_ps[MAX_ISRC];
+  short src_ch[MAX_ISRC];
+  short src_qp[MAX_ISRC];  // padded chunk count (multiple of 4)
+  int src_pixb[MAX_ISRC];  // LDS pixel stride in bytes
+  int nsrc;
+  const char* wpack;
+  const float* bias;
+  char* out;
+  long long out_ps;
+  char* out_pre;
+  const char* res;
+  long long res_ps;
+  const char* aux;
+  long long aux_ps;
+  int N, H, W, Cout, tiles_x, tiles_y;
+  long long M;
+  int act;
+  float slope, alpha;
+  int actgrad, ps;
+  int kt;          // total k-steps over all sources
+  int halo_bytes;  // LDS bytes reserved for the halo tile
+};
+
+template <typename T, int KS, int MT, int NTB>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
+  constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
+  constexpr int TH = 4 * MT;
+  constexpr int TWH = (KS == 3) ? 18 : 16;
+  constexpr int THH = (KS == 3) ? TH + 2 : TH;
+  constexpr int COB = NTB * 16;
+  constexpr int STAGEB = KSTG * 4 * COB * CB;
+  constexpr int KK = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + a.halo_bytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  int n = 0, ty = 0, tx = 0;
+  long long m0 = 0;
+  if (KS == 3) {
+    int bid = blockIdx.x;
+    tx = bid % a.tiles_x;
+    int r = bid / a.tiles_x;
+    ty = r % a.tiles_y;
+    n = r / a.tiles_y;
+  } else {
+    m0 = (long long)blockIdx.x * (64 * MT);
+  }
+
+  f32x4 acc[NTB][MT];
+#pragma unroll
+  for (int ct = 0; ct < NTB; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nstages = (a.kt + KSTG - 1) / KSTG;
+  auto issue_w = [&](int stage) {
+    const char* gsrc = a.wpack + ((long long)cb * a.kt + (long long)stage * KSTG) * (4 * COB * CB);
+    int nks = a.kt - stage * KSTG;
+    if (nks > KSTG) nks = KSTG;
+    const int bytes = nks * 4 * COB * CB;  // multiple of 1024
+    char* dst = wbuf + (stage & 1) * STAGEB;
+    for (int off = wave * 1024; off < bytes; off += 4 * 1024)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off + lane * 16), LDS_PTR(dst + off), 16, 0, 0);
+  };
+
+  issue_w(0);
+  int ksg = 0;  // global k-step
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int ch = a.src_ch[s], pixb = a.src_pixb[s];
+    const int CH = ch >> 3;  // chunks per tap
+    const int Q = KK * CH;
+    __syncthreads();  // everyone is done reading the previous halo tile
+    {                 // ---- stage the halo tile of this source
+      const char* sp = a.src[s];
+      const long long ps_b = a.src_ps[s] * ES;
+      const int vpp = ch * ES / 16;  // 16-byte vectors per pixel
+      const int total = THH * TWH * vpp;
+      for (int i = tid; i < total; i += 256) {
+        const int p = i / vpp, v = i - p * vpp;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (KS == 3) {
+          const int r = p / TWH, c = p - r * TWH;
+          const int y = ty * TH + r - 1, x = tx * 16 + c - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+            val = *reinterpret_cast<const uint4*>(sp + (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16);
+        } else {
+          const long long m = m0 + p;
+          if (m < a.M) val = *reinterpret_cast<const uint4*>(sp + m * ps_b + v * 16);
+        }
+        *reinterpret_cast<uint4*>(halo + p * pixb + v * 16) = val;
+      }
+    }
+    __syncthreads();
+
+    // per-lane pixel base offsets in the halo tile
+    int pixoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wave * MT + mt;
+      pixoff[mt] = (KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb;
+    }
+    // (tap, c8) of this lane group's chunk q = 4*ks + g, advanced incrementally
+    int tap = 0, c8 = g;
+    while (c8 >= CH) { c8 -= CH; ++tap; }
+
+    const int nks = a.src_qp[s] >> 2;
+    for (int ks = 0; ks < nks; ++ks, ++ksg) {
+      if (ksg % KSTG == 0) {
+        // stage ksg/KSTG must have landed; all waves are past stage-1's reads -> its buffer is free
+        __syncthreads();  // (emits vmcnt(0) for the outstanding LDS-DMA)
+        const int st = ksg / KSTG;
+        if (st + 1 < nstages) issue_w(st + 1);
+      }
+      int t2 = tap, c2 = c8;
+      if (t2 >= KK) { t2 = KK - 1; c2 = CH - 1; }  // zero-weight padding chunk: read any valid address
+      const int ky = (KS == 3) ? t2 / 3 : 0;
+      const int kx = (KS == 3) ? t2 - 3 * ky : 0;
+      const int boff = (ky * TWH + kx) * pixb + c2 * CB;
+      const char* wst = wbuf + ((ksg / KSTG) & 1) * STAGEB + ((ksg % KSTG) * 4 + g) * (COB * CB) + px * CB;
+
+      if constexpr (ES == 2) {
+        bf16x8 xb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xb[mt] = *reinterpret_cast<const bf16x8*>(halo + pixoff[mt] + boff);
+#pragma unroll
+        for (int ct = 0; ct < NTB; ++ct) {
+          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wst + ct * 16 * CB);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[mt], acc[ct][mt], 0, 0, 0);
+        }
+      } else {
+        float xb[MT][8];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4 lo = *reinterpret_cast<const float4*>(halo + pixoff[mt] + boff);
+          const float4 hi = *reinterpret_cast<const float4*>(halo + pixoff[mt] + boff + 16);
+          xb[mt][0] = lo.x; xb[mt][1] = lo.y; xb[mt][2] = lo.z; xb[mt][3] = lo.w;
+          xb[mt][4] = hi.x; xb[mt][5] = hi.y; xb[mt][6] = hi.z; xb[mt][7] = hi.w;
+        }
+#pragma unroll
+        for (int ct = 0; ct < NTB; ++ct) {
+          const float4 lo = *reinterpret_cast<const float4*>(wst + ct * 16 * CB);
+          const float4 hi = *reinterpret_cast<const float4*>(wst + ct * 16 * CB + 16);
+          const float wa[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[mt][j], acc[ct][mt], 0, 0, 0);
+        }
+      }
+      c8 += 4;
+      while (c8 >= CH) { c8 -= CH; ++tap; }
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------- epilogue
+  T* out = reinterpret_cast<T*>(a.out);
+  T* out_pre = reinterpret_cast<T*>(a.out_pre);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  const T* aux = reinterpret_cast<const T*>(a.aux);
+  const bool vec_ok = ((a.Cout & 3) == 0) && ((a.out_ps & 3) == 0) && (!res || (a.res_ps & 3) == 0) &&
+                      (!aux || (a.aux_ps & 3) == 0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long long pix;
+    bool valid;
+    int y = 0, x = 0;
+    if (KS == 3) {
+      y = ty * TH + wave * MT + mt;
+      x = tx * 16 + px;
+      valid = (y < a.H) && (x < a.W);
+      pix = ((long long)n * a.H + y) * a.W + x;
+    } else {
+      pix = m0 + (wave * MT + mt) * 16 + px;
+      valid = pix < a.M;
+      if (a.ps) {
+        x = (int)(pix % a.W);
+        const long long t = pix / a.W;
+        y = (int)(t % a.H);
+        n = (int)(t / a.H);
+      }
+    }
+    if (!valid) continue;
+#pragma unroll
+    for (int ct = 0; ct < NTB; ++ct) {
+      const int co0 = cb * COB + ct * 16 + g * 4;
+      if (co0 >= a.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + r;
+        v[r] = acc[ct][mt][r] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
+      }
+      const bool full = vec_ok && (co0 + 3 < a.Cout);
+      if (out_pre) {
+        if (full) store4(out_pre + pix * a.out_ps + co0, v);
+        else
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < a.Cout) out_pre[pix * a.out_ps + co0 + r] = from_f32<T>(v[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        if (a.act == VMG_ACT_RELU) t = fmaxf(t, 0.f);
+        else if (a.act == VMG_ACT_LRELU) t = t > 0.f ? t : t * a.slope;
+        else if (a.act == VMG_ACT_GELU) t = gelu_erf(t);
+        v[r] = t * a.alpha;
+      }
+      if (aux) {
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+        if (full) load4(aux + pix * a.aux_ps + co0, u);
+        else
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < a.Cout) u[r] = to_f32(aux[pix * a.aux_ps + co0 + r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float d = 1.f;
+          if (a.actgrad == 1) d = u[r] > 0.f ? 1.f : 0.f;
+          else if (a.actgrad == 2) d = u[r] > 0.f ? 1.f : a.slope;
+          else if (a.actgrad == 3) d = gelu_erf_grad(u[r]);
+          v[r] *= d;
+        }
+      }
+      if (res) {
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+        if (full) load4(res + pix * a.res_ps + co0, u);
+        else
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < a.Cout) u[r] = to_f32(res[pix * a.res_ps + co0 + r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += u[r];
+      }
+      if (a.ps) {
+        // torch PixelShuffle(2): channel co = c*4 + i*2 + j -> out[n, 2y+i, 2x+j, c]
+        const int c = co0 >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (co0 + r >= a.Cout) continue;
+          const long long op = ((long long)n * (2 * a.H) + (2 * y + (r >> 1))) * (2 * a.W) + (2 * x + (r & 1));
+          out[op * a.out_ps + c] = from_f32<T>(v[r]);
+        }
+      } else if (full) {
+        store4(out + pix * a.out_ps + co0, v);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (co0 + r < a.Cout) out[pix * a.out_ps + co0 + r] = from_f32<T>(v[r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- packing
+struct PackK {
+  const float* w;
+  char* out;
+  int O, I, ks, o0, on, nsrc, transpose_flip, cob, ncb, kt;
+  short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_qoff[MAX_ISRC], src_qp[MAX_ISRC];
+};
+
+template <typename T>
+__global__ void conv_pack_kernel(const PackK p) {
+  // one thread per packed element: [cb][q][co][8]
+  const long long total = (long long)p.ncb * p.kt * 4 * p.cob * 8;
+  const int KK = p.ks * p.ks;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long long r = i >> 3;
+    const int co = (int)(r % p.cob);
+    r /= p.cob;
+    const int q = (int)(r % (p.kt * 4));
+    const int cb = (int)(r / (p.kt * 4));
+    int s = 0;
+    while (s + 1 < p.nsrc && q >= p.src_qoff[s + 1]) ++s;
+    const int ql = q - p.src_qoff[s];
+    const int CH = p.src_ch[s] >> 3;
+    const int col = cb * p.cob + co;  // output channel within [0, on)
+    float v = 0.f;
+    if (ql < KK * CH && col < p.on) {
+      const int tap = ql / CH, c = (ql - tap * CH) * 8 + e;
+      const int kc = p.src_off[s] + c;  // K-side channel
+      const int oc = p.o0 + col;        // output-side channel
+      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
+      else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
+    }
+    reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
+  }
+}
+
+// internal channel-block splitting: the SAME rule for packing and for the conv call
+int expand_sources(int nsrc, const int* off, const int* ch, short* xoff, short* xch, int* parent) {
+  int k = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    int parts = 1;
+    while (ch[s] / parts > CBMAX || ch[s] % (8 * parts) != 0) {
+      ++parts;
+      if (parts > ch[s] / 8) return -1;
+    }
+    const int c = ch[s] / parts;
+    for (int j = 0; j < parts; ++j) {
+      if (k >= MAX_ISRC) return -1;
+      xoff[k] = (short)((off ? off[s] : 0) + j * c);
+      xch[k] = (short)c;
+      if (parent) parent[k] = s;
+      ++k;
+    }
+  }
+  return k;
+}
+
+// smallest LDS pixel stride (bytes) >= ch*ES that keeps the 16-pixel ds_read_b128 lane groups conflict-free
+int choose_pixb(int ch, int es, int cb) {
+  static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                 {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                 {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                 {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  int best = ch * es, bestc = 1 << 30;
+  for (int pad = 0; pad <= 240; pad += 16) {
+    const int pixb = ch * es + pad;
+    int worst = 0;
+    for (int gi = 0; gi < 4; ++gi) {
+      int cnt[16] = {0};
+      for (int j = 0; j < 16; ++j) {
+        const int l = grp[gi][j];
+        const int addr = (l & 15) * pixb + (l >> 4) * cb;
+        int c = ++cnt[(addr >> 4) & 15];
+        if (c > worst) worst = c;
+      }
+    }
+    if (worst < bestc) { bestc = worst; best = pixb; }
+    if (worst == 1) break;
+  }
+  return best;
+}
+
+template <typename T, int KS, int MT, int NTB>
+int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
+  constexpr int CB = ElemTraits<T>::CHUNKB;
+  const int lds = k.halo_bytes + 2 * KSTG * 4 * NTB * 16 * CB;
+  VMG_CHECK(lds <= 160 * 1024, "conv: LDS request %d B exceeds 160 KiB", lds);
+  auto fn = conv_igemm_kernel<T, KS, MT, NTB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
+  VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, k);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int KS, int MT>
+int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
+  switch (ntb) {
+    case 1: return launch_conv<T, KS, MT, 1>(k, ncb, st);
+    case 4: return launch_conv<T, KS, MT, 4>(k, ncb, st);
+    case 7: return launch_conv<T, KS, MT, 7>(k, ncb, st);
+    case 8: return launch_conv<T, KS, MT, 8>(k, ncb, st);
+    case 9: return launch_conv<T, KS, MT, 9>(k, ncb, st);
+  }
+  vmg_set_error("conv: cout_tiles must be 1, 4, 7, 8 or 9 (got %d)", ntb);
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles) {
+  short xoff[MAX_ISRC], xch[MAX_ISRC];
+  const int n = expand_sources(nsrc, nullptr, src_ch, xoff, xch, nullptr);
+  if (n < 0 || cout_tiles <= 0) return -1;
+  int64_t qp = 0;
+  for (int s = 0; s < n; ++s) qp += (ks * ks * (xch[s] / 8) + 3) / 4 * 4;
+  const int cob = cout_tiles * 16;
+  const int ncb = (on + cob - 1) / cob;
+  return (int64_t)ncb * qp * cob * 8 * (dtype == VMG_BF16 ? 2 : 4);
+}
+
+extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                             const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream) {
+  VMG_CHECK(ks == 1 || ks == 3, "conv_pack: ks must be 1 or 3");
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_pack: bad dtype");
+  VMG_CHECK(nsrc >= 1 && nsrc <= 4, "conv_pack: nsrc must be 1..4");
+  VMG_CHECK(!transpose_flip || nsrc == 1, "conv_pack: data-gradient packing takes one K slice");
+  PackK p;
+  memset(&p, 0, sizeof(p));
+  const int n = expand_sources(nsrc, src_off, src_ch, p.src_off, p.src_ch, nullptr);
+  VMG_CHECK(n > 0, "conv_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
+  int q = 0;
+  for (int s = 0; s < n; ++s) {
+    p.src_qoff[s] = (short)q;
+    p.src_qp[s] = (short)((ks * ks * (p.src_ch[s] / 8) + 3) / 4 * 4);
+    q += p.src_qp[s];
+  }
+  // bounds of the slices against the weight tensor
+  const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
+  for (int s = 0; s < n; ++s) VMG_CHECK(p.src_off[s] >= 0 && p.src_off[s] + p.src_ch[s] <= kdim, "conv_pack: K slice out of range");
+  VMG_CHECK(o0 >= 0 && o0 + on <= odim, "conv_pack: output slice out of range");
+  p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = ks; p.o0 = o0; p.on = on; p.nsrc = n;
+  p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.kt = q / 4;
+  const long long total = (long long)p.ncb * q * p.cob * 8;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
+  VMG_CHECK(d != nullptr, "conv_fwd: null descriptor");
+  VMG_CHECK(d->ks == 1 || d->ks == 3, "conv_fwd: ks must be 1 or 3");
+  VMG_CHECK(d->dtype == VMG_F32 || d->dtype == VMG_BF16, "conv_fwd: bad dtype");
+  VMG_CHECK(d->nsrc >= 1 && d->nsrc <= 4, "conv_fwd: nsrc must be 1..4");
+  VMG_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv_fwd: bad shape");
+  VMG_CHECK(d->packed && d->out, "conv_fwd: null packed weights / output");
+  VMG_CHECK(!d->pixel_shuffle || (d->Cout % 4 == 0), "conv_fwd: pixel_shuffle needs Cout %% 4 == 0");
+  VMG_CHECK(!(d->actgrad != 0 && d->aux == nullptr), "conv_fwd: actgrad without aux");
+  const int es = d->dtype == VMG_BF16 ? 2 : 4, cbytes = es * 8;
+  ConvK k;
+  memset(&k, 0, sizeof(k));
+  short xoff[MAX_ISRC];
+  int parent[MAX_ISRC];
+  const int n = expand_sources(d->nsrc, nullptr, d->src_ch, xoff, k.src_ch, parent);
+  VMG_CHECK(n > 0, "conv_fwd: source channel counts must be multiples of 8");
+  int mt = d->mt;
+  if (d->dtype == VMG_F32) mt = 1;
+  const long long M = (long long)d->N * d->H * d->W;
+  const int ntb = d->cout_tiles;
+  const int ncb = cdiv(d->Cout, ntb * 16);
+  if (mt == 0) {
+    // two 16-pixel rows per wave halve the weight re-reads from LDS, but only if the grid still fills 256 CUs
+    const long long blk2 = (d->ks == 3) ? (long long)d->N * cdiv(d->H, 8) * cdiv(d->W, 16) : cdiv64(M, 128);
+    mt = (blk2 * ncb >= 224) ? 2 : 1;
+  }
+  VMG_CHECK(mt == 1 || mt == 2, "conv_fwd: mt must be 1 or 2");
+  const int TH = 4 * mt, TWH = d->ks == 3 ? 18 : 16, THH = d->ks == 3 ? TH + 2 : TH;
+  int kt = 0, halo = 0;
+  for (int s = 0; s < n; ++s) {
+    const int par = parent[s];
+    VMG_CHECK(d->src[par] != nullptr, "conv_fwd: null source %d", par);
+    VMG_CHECK(d->src_ps[par] >= d->src_ch[par] && (d->src_ps[par] * es) % 16 == 0, "conv_fwd: source pixel stride must be >= channels and 16-byte aligned");
+    VMG_CHECK(((uintptr_t)d->src[par]) % 16 == 0, "conv_fwd: source pointer must be 16-byte aligned");
+    k.src[s] = (const char*)d->src[par] + (long long)xoff[s] * es;
+    k.src_ps[s] = d->src_ps[par];
+    k.src_qp[s] = (short)((d->ks * d->ks * (k.src_ch[s] / 8) + 3) / 4 * 4);
+    k.src_pixb[s] = choose_pixb(k.src_ch[s], es, cbytes);
+    kt += k.src_qp[s] / 4;
+    const int hb = THH * TWH * k.src_pixb[s];
+    if (hb > halo) halo = hb;
+  }
+  k.nsrc = n;
+  k.wpack = (const char*)d->packed; k.bias = d->bias;
+  k.out = (char*)d->out; k.out_ps = d->out_ps; k.out_pre = (char*)d->out_pre;
+  k.res = (const char*)d->res; k.res_ps = d->res_ps; k.aux = (const char*)d->aux; k.aux_ps = d->aux_ps;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.M = M;
+  k.tiles_x = cdiv(d->W, 16); k.tiles_y = cdiv(d->H, TH);
+  k.act = d->act; k.slope = d->slope; k.alpha = d->alpha; k.actgrad = d->aux ? d->actgrad : 0; k.ps = d->pixel_shuffle;
+  k.kt = kt; k.halo_bytes = (halo + 15) & ~15;
+  VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == VMG_BF16) {
+    if (d->ks == 3) return mt == 2 ? dispatch_ntb<bf16, 3, 2>(k, ntb, ncb, st) : dispatch_ntb<bf16, 3, 1>(k, ntb, ncb, st);
+    return mt == 2 ? dispatch_ntb<bf16, 1, 2>(k, ntb, ncb, st) : dispatch_ntb<bf16, 1, 1>(k, ntb, ncb, st);
+  }
+  if (d->ks == 3) return dispatch_ntb<float, 3, 1>(k, ntb, ncb, st);
+  return dispatch_ntb<float, 1, 1>(k, ntb, ncb, st);
+}

@@ -1,0 +1,88 @@
+"""ctypes binding of libvmg_hip.so (the C-ABI declared in include/vmg_hip.h).
+
+The product path has no CPU or eager fallback: if the library is missing or an entry point fails, this
+module raises.  Build it with ``python -m vmg_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvmg_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int), ("ks", c_int), ("cout_tiles", c_int),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int),
+        ("nsrc", c_int),
+        ("src", c_void_p * 4), ("src_ps", c_int64 * 4), ("src_ch", c_int * 4),
+        ("packed", c_void_p), ("bias", c_void_p),
+        ("out", c_void_p), ("out_ps", c_int64), ("out_pre", c_void_p),
+        ("res", c_void_p), ("res_ps", c_int64),
+        ("aux", c_void_p), ("aux_ps", c_int64),
+        ("act", c_int), ("slope", c_float), ("alpha", c_float),
+        ("actgrad", c_int), ("pixel_shuffle", c_int), ("mt", c_int),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol of include/vmg_hip.h must be listed (tests/test_abi.py checks)
+SIGNATURES = {
+    "vmg_last_error": (c_char_p, []),
+    "vmg_version": (c_int, []),
+    "vmg_max_lds_bytes": (c_int, []),
+    "vmg_conv_pack_bytes": (c_int64, [c_int, c_int, c_int, c_int, POINTER(c_int), c_int]),
+    "vmg_conv_pack": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
+                              c_int, c_int, c_void_p, c_void_p]),
+    "vmg_conv_fwd": (c_int, [POINTER(ConvDesc), c_void_p]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: the VMG hot path has no fallback. Run `python -m vmg_amd.build`.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed ({rc}): {lib().vmg_last_error().decode()}")
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise HipError(f"unsupported activation dtype {t}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipError("the VMG HIP path needs device tensors (there is no CPU fallback)")

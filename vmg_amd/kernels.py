@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C-ABI (no autograd here; see functional.py).
+
+Every function takes/returns torch device tensors in channels-last layout and enqueues on torch's current
+stream.  Shapes are validated on the host before a kernel is launched.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+from .hip import ConvDesc, HipError
+
+
+def _intarr(v: Sequence[int]):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def cout_tiles_for(cout: int) -> int:
+    """16-channel tiles per workgroup: 9 covers C = 144/288/576 exactly, 7 covers 112/224/448, 8 covers 128/256;
+    otherwise the candidate with the least padding."""
+    t = (cout + 15) // 16
+    if t <= 1:
+        return 1
+    if t <= 4:
+        return 4
+    best, waste = 9, None
+    for cand in (9, 8, 7):
+        w = (t + cand - 1) // cand * cand - t
+        if waste is None or w < waste:
+            best, waste = cand, w
+    return best
+
+
+class PackedConv:
+    """Packed (device) weights of one convolution / linear for one direction (forward or data-gradient)."""
+
+    __slots__ = ("buf", "dtype", "ks", "cout", "src_ch", "cout_tiles")
+
+    def __init__(self, buf, dtype, ks, cout, src_ch, cout_tiles):
+        self.buf, self.dtype, self.ks, self.cout, self.src_ch, self.cout_tiles = buf, dtype, ks, cout, list(src_ch), cout_tiles
+
+
+def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None,
+                     src_off: Optional[Sequence[int]] = None, o0: int = 0, on: Optional[int] = None,
+                     transpose_flip: bool = False, out: Optional[torch.Tensor] = None) -> PackedConv:
+    """w: fp32 (O, I, KS, KS) or (O, I).  Forward pack: K slices = src_off/src_ch over I, outputs O[o0:o0+on).
+    Data-gradient pack (transpose_flip): outputs I[o0:o0+on), K = O[src_off[0]:+src_ch[0])."""
+    hip.require_cuda(w)
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        raise HipError("pack_conv_weight expects a contiguous fp32 weight")
+    if w.dim() == 2:
+        O, I, ks = w.shape[0], w.shape[1], 1
+    elif w.dim() == 4 and w.shape[2] == w.shape[3]:
+        O, I, ks = w.shape[0], w.shape[1], w.shape[2]
+    else:
+        raise HipError(f"unsupported weight shape {tuple(w.shape)}")
+    kdim, odim = (O, I) if transpose_flip else (I, O)
+    if src_ch is None:
+        src_ch, src_off = [kdim], [0]
+    if src_off is None:
+        src_off, acc = [], 0
+        for c in src_ch:
+            src_off.append(acc)
+            acc += c
+    if on is None:
+        on = odim - o0
+    tiles = cout_tiles_for(on)
+    code = hip.dtype_code(dtype)
+    l = hip.lib()
+    nbytes = l.vmg_conv_pack_bytes(code, ks, on, len(src_ch), _intarr(src_ch), tiles)
+    if nbytes <= 0:
+        raise HipError(f"vmg_conv_pack_bytes rejected channels {list(src_ch)} (must be multiples of 8)")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    elif out.numel() * out.element_size() < nbytes:
+        raise HipError("pack buffer too small")
+    hip.check(l.vmg_conv_pack(code, w.data_ptr(), O, I, ks, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch),
+                              1 if transpose_flip else 0, tiles, out.data_ptr(), hip.stream_ptr()), "vmg_conv_pack")
+    return PackedConv(out, dtype, ks, on, src_ch, tiles)
+
+
+def _pix_stride(t: torch.Tensor) -> int:
+    """Pixel stride (elements) of a channels-last tensor whose leading dims are dense over pixels."""
+    if t.stride(-1) != 1:
+        raise HipError("channels must be the fastest dimension")
+    ps = t.stride(-2)
+    # leading dims must be a dense pixel enumeration with that stride
+    expect = ps
+    for d in range(t.dim() - 2, -1, -1):
+        if t.size(d) != 1 and t.stride(d) != expect:
+            raise HipError(f"tensor of shape {tuple(t.shape)} / strides {t.stride()} is not a dense pixel array")
+        expect *= t.size(d)
+    return ps
+
+
+def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[torch.Tensor], N: int, H: int, W: int,
+                 act: int = hip.ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
+                 aux: Optional[torch.Tensor] = None, actgrad: int = 0, pixel_shuffle: bool = False,
+                 out: Optional[torch.Tensor] = None, out_pre: Optional[torch.Tensor] = None, want_pre: bool = False,
+                 mt: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Runs vmg_conv_fwd.  srcs: channels-last tensors (..., C_s) covering N*H*W pixels each (channel slices of
+    wider tensors are fine).  Returns (out, out_pre)."""
+    if len(srcs) != len(pw.src_ch):
+        raise HipError(f"conv expects {len(pw.src_ch)} sources, got {len(srcs)}")
+    x0 = srcs[0]
+    hip.require_cuda(*srcs, bias, res, aux, out)
+    dt = x0.dtype
+    if dt != pw.dtype:
+        raise HipError(f"activation dtype {dt} != packed weight dtype {pw.dtype}")
+    M = N * H * W
+    d = ConvDesc()
+    d.dtype, d.ks, d.cout_tiles = hip.dtype_code(dt), pw.ks, pw.cout_tiles
+    d.N, d.H, d.W, d.Cout = N, H, W, pw.cout
+    d.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        if s.dtype != dt or s.shape[-1] != pw.src_ch[i] or s.numel() // s.shape[-1] != M:
+            raise HipError(f"source {i}: shape {tuple(s.shape)} / dtype {s.dtype} does not match conv (M={M}, C={pw.src_ch[i]}, {dt})")
+        d.src[i] = s.data_ptr()
+        d.src_ps[i] = _pix_stride(s)
+        d.src_ch[i] = pw.src_ch[i]
+    d.packed = pw.buf.data_ptr()
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != pw.cout or not bias.is_contiguous():
+            raise HipError("bias must be contiguous fp32 of length Cout")
+        d.bias = bias.data_ptr()
+    if pixel_shuffle:
+        oshape = (N, 2 * H, 2 * W, pw.cout // 4)
+    else:
+        oshape = (N, H, W, pw.cout)
+    if out is None:
+        out = torch.empty(oshape, dtype=dt, device=x0.device)
+    elif out.dtype != dt or out.numel() // out.shape[-1] != (4 * M if pixel_shuffle else M) or out.shape[-1] != oshape[-1]:
+        raise HipError(f"bad output tensor {tuple(out.shape)} for conv output {oshape}")
+    d.out, d.out_ps = out.data_ptr(), _pix_stride(out)
+    if want_pre and out_pre is None:
+        if pixel_shuffle:
+            raise HipError("out_pre is not available with pixel_shuffle")
+        out_pre = torch.empty(oshape, dtype=dt, device=x0.device)
+    if out_pre is not None:
+        if _pix_stride(out_pre) != d.out_ps or out_pre.shape[-1] != pw.cout or out_pre.dtype != dt:
+            raise HipError("out_pre must have the layout of out")
+        d.out_pre = out_pre.data_ptr()
+    for name, t in (("res", res), ("aux", aux)):
+        if t is None:
+            continue
+        if pixel_shuffle:
+            raise HipError(f"{name} is not supported together with pixel_shuffle")
+        if t.dtype != dt or t.shape[-1] != pw.cout or t.numel() // t.shape[-1] != M:
+            raise HipError(f"{name}: shape {tuple(t.shape)} does not match conv output")
+        setattr(d, name, t.data_ptr())
+        setattr(d, name + "_ps", _pix_stride(t))
+    d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt = act, slope, alpha, actgrad, int(pixel_shuffle), mt
+    hip.check(hip.lib().vmg_conv_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_conv_fwd")
+    return out, out_pre
