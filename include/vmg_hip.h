@@ -111,6 +111,26 @@ int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_
                    int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / normalisation kernels (HBM-bound, one pass, 16-byte vectors).
+ *
+ * vmg_act_bwd        out = dy * alpha * act'(ref)   ref = output for RELU/LRELU, pre-activation for GELU.
+ *                    Backward of the activations fused in the conv epilogue (function.py:72,632; trajectory.py:33,188).
+ * vmg_pixel_shuffle  to_depth = 0: (N,H,W,4c) -> (N,2H,2W,c) in torch nn.PixelShuffle(2) channel order
+ *                    (models/vmg.py:380,629-630); to_depth = 1: the inverse (its backward).
+ * vmg_layernorm_fwd  y = (x - mean) * rstd * w + b over the last dim C of (M, C) rows, eps inside the sqrt; mean / rstd
+ *                    (fp32, M each) are written when non-null.  nn.LayerNorm at function.py:1164,1195; layers.py:768-775;
+ *                    swin_3d.py:717,741.
+ * vmg_layernorm_bwd  dx, and dw += sum dy * xhat, db += sum dy (fp32 atomics).
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
+                void* stream);
+int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream);
+int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t M,
+                      int C, float eps, void* stream);
+int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,
+                      float* dw, float* db, int64_t M, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,60 @@ def test_bad_arguments_raise():
         K.conv_forward([torch.randn(1, 8, 8, 144, device="cuda")], pw, None, 1, 8, 8)  # fp32 activations vs bf16 pack
     with pytest.raises(hip.HipError):
         K.conv_forward([torch.randn(1, 8, 8, 144)], pw, None, 1, 8, 8)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 12, 40, 144, 144, 3), (1, 9, 70, 64, 3, 3), (2, 16, 16, 288, 144, 3), (1, 1, 1000, 144, 288, 1),
+                                   (1, 1, 777, 576, 144, 1), (1, 20, 20, 8, 144, 3)])
+def test_conv_wgrad(dtype, shape):
+    """dW, db accumulate (+=) scale * autograd gradients of the oracle conv."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, ks = shape
+    x = R.seeded((N, H, W, Ci), 21)
+    dy = R.seeded((N, H, W, Co), 22)
+    w = torch.zeros(Co, Ci, ks, ks, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    y = O.conv_nhwc(_q(x, dtype), w, b, ks // 2)
+    gw, gb = torch.autograd.grad(y, (w, b), _q(dy, dtype))
+    init_w, init_b = R.seeded((Co, Ci, ks, ks), 23), R.seeded((Co,), 24)
+    dW, db = init_w.clone().cuda(), init_b.clone().cuda()
+    K.conv_wgrad(x.cuda().to(dtype), dy.cuda().to(dtype), dW, db, ks, N, H, W, scale=0.5)
+    scale = max(1.0, float(gw.abs().max()))
+    tol = 2e-4 if dtype == torch.float32 else 2e-3  # bf16 inputs are exact on both sides; fp32 accumulation order differs
+    err = float((dW.cpu() - (init_w + 0.5 * gw)).abs().max())
+    assert err <= tol * scale, f"dW err {err} scale {scale}"
+    errb = float((db.cpu() - (init_b + 0.5 * gb)).abs().max())
+    assert errb <= tol * max(1.0, float(gb.abs().max())), f"db err {errb}"
+
+
+def test_conv_wgrad_slices():
+    """Gradient of a weight slice: W[o0:o0+Co, i0:i0+Ci] of a wider parameter (virtual concat / grouped conv)."""
+    hip, K, O, R = _setup()
+    N, H, W = 1, 16, 32
+    x, dy = R.seeded((N, H, W, 288), 25), R.seeded((N, H, W, 144), 26)
+    w = torch.zeros(144, 288, 3, 3, requires_grad=True)
+    (gw,) = torch.autograd.grad(O.conv_nhwc(x, w, None, 1), w, dy)
+    dW = torch.zeros(144, 288, 3, 3, device="cuda")
+    xd, dyd = x.cuda(), dy.cuda()
+    K.conv_wgrad(xd[..., :144], dyd, dW, None, 3, N, H, W, i0=0)
+    K.conv_wgrad(xd[..., 144:], dyd, dW, None, 3, N, H, W, i0=144)
+    assert float((dW.cpu() - gw).abs().max()) <= 2e-4 * max(1.0, float(gw.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(5, 256, 256, 64, 64, 0), (5, 256, 256, 128, 64, 0), (5, 256, 256, 64, 64, 1), (28, 64, 64, 144, 144, 1)])
+def test_conv_repeatable_under_load(shape):
+    """Regression: the LDS-DMA weight ring must be waited for explicitly (hipcc does not drain global_load_lds at
+    __syncthreads()).  The race only shows when several workgroups share a CU, i.e. on large grids: results must
+    be bitwise repeatable and correct there."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, mt = shape
+    dt = torch.bfloat16
+    x = R.seeded((N, H, W, Ci), 31).cuda().to(dt)
+    w = R.seeded((Co, Ci, 3, 3), 32, (Ci * 9) ** -0.5).cuda()
+    pw = K.pack_conv_weight(w, dt)
+    ref = F.conv2d(x[:1].float().permute(0, 3, 1, 2).cpu(), w.to(dt).float().cpu(), None, padding=1).permute(0, 2, 3, 1)
+    first = K.conv_forward([x], pw, None, N, H, W, mt=mt)[0]
+    assert float((first[:1].float().cpu() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+    for _ in range(10):
+        again = K.conv_forward([x], pw, None, N, H, W, mt=mt)[0]
+        assert torch.equal(first, again)

@@ -134,8 +134,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
     const int nks = a.src_qp[s] >> 2;
     for (int ks = 0; ks < nks; ++ks, ++ksg) {
       if (ksg % KSTG == 0) {
-        // stage ksg/KSTG must have landed; all waves are past stage-1's reads -> its buffer is free
-        __syncthreads();  // (emits vmcnt(0) for the outstanding LDS-DMA)
+        // stage ksg/KSTG must have landed; all waves are past stage-1's reads -> its buffer is free.
+        // hipcc does NOT drain LDS-DMA (global_load_lds) at __syncthreads(): without this explicit wait the
+        // barrier is a bare s_barrier and waves read the stage before it has landed (seen as run-to-run
+        // differences only when several workgroups share a CU).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         const int st = ksg / KSTG;
         if (st + 1 < nstages) issue_w(st + 1);
       }
@@ -457,11 +461,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   const long long M = (long long)d->N * d->H * d->W;
   const int ntb = d->cout_tiles;
   const int ncb = cdiv(d->Cout, ntb * 16);
-  if (mt == 0) {
-    // two 16-pixel rows per wave halve the weight re-reads from LDS, but only if the grid still fills 256 CUs
-    const long long blk2 = (d->ks == 3) ? (long long)d->N * cdiv(d->H, 8) * cdiv(d->W, 16) : cdiv64(M, 128);
-    mt = (blk2 * ncb >= 224) ? 2 : 1;
-  }
+  if (mt == 0) mt = 1;  // measured (tools/bench_conv.py): one 16-pixel row per wave keeps 2 workgroups per CU and wins everywhere
   VMG_CHECK(mt == 1 || mt == 2, "conv_fwd: mt must be 1 or 2");
   const int TH = 4 * mt, TWH = d->ks == 3 ? 18 : 16, THH = d->ks == 3 ? TH + 2 : TH;
   int kt = 0, halo = 0;

@@ -1,0 +1,298 @@
+// Weight / bias gradient of the stride-1 "same" convolution (KS = 3 or 1), channels-last, gfx950.
+//
+//   dW[o][i][tap] += scale * sum_pixels dY[p][o] * X[p + tap][i]          (fp32, OIHW, atomically accumulated)
+//
+// GEMM view: M = output channels, N = (tap, input channel), K = pixels.  Both operands are stored pixel-major
+// (channels-last), but the MFMA wants 8 consecutive K (= pixels) per lane, i.e. the TRANSPOSE of what is in
+// memory.  gfx950's ds_read_b64_tr_b16 does that transpose on the LDS read path for 16-bit data: tiles are
+// staged in LDS exactly as they lie in HBM ([pixel][channel], 16-byte vector copies) and each operand fragment
+// is two transposed reads.  The tap shift is a row (pixel) offset of the transposed read, so one staged X tile
+// with a 1-pixel halo serves all 9 taps.  fp32 uses v_mfma_f32_16x16x4_f32, whose operands are single
+// elements (plain ds_read_b32).
+//
+// Work split: blockIdx.x = block of CT*16 output channels, blockIdx.y = block of IT*16 input channels,
+// blockIdx.z = K split.  A K unit is 32 consecutive pixels of one image row.  Each of the 4 waves walks its own
+// units through a wave-private LDS tile (no workgroup barriers in the main loop; next unit's global loads are in
+// flight while the current one is multiplied).  At the end the 4 waves' accumulators are summed with LDS float
+// atomics into a [co][ci][tap] image = the OIHW order, and written out with coalesced global float atomics.
+#include "common.h"
+
+namespace {
+
+struct WgradK {
+  const char* x;
+  long long x_ps;
+  int Cin;
+  const char* dy;
+  long long dy_ps;
+  int Cout;
+  float* dW;
+  int I_total, o0, i0;
+  float* db;
+  float scale;
+  int N, H, W, SEG;
+  long long M, U;
+  int S;
+  int vec_ok;  // 16-byte vector loads are legal for both operands
+};
+
+template <typename T, int KS, int CT, int IT>
+struct WgradCfg {
+  static constexpr int ES = ElemTraits<T>::ES;
+  static constexpr int KK = KS * KS;
+  static constexpr int XR = KS, XW = 32 + KS - 1;
+  static constexpr int DYC = CT * 16, XC = IT * 16;
+  static constexpr int DY_RS = DYC * ES + 16, X_RS = XC * ES + 16;  // LDS row (= pixel) strides in bytes
+  static constexpr int DY_BYTES = 32 * DY_RS, X_BYTES = XR * XW * X_RS;
+  static constexpr int WAVE_BYTES = (DY_BYTES + X_BYTES + 15) & ~15;
+  static constexpr int RED_RS = XC * KK + 2;  // floats per output-channel row of the reduction image
+  static constexpr int RED_BYTES = (DYC * RED_RS + DYC) * 4;
+  static constexpr int LDS_BYTES = 4 * WAVE_BYTES + RED_BYTES;
+  static constexpr int VPL = 16 / ES;                        // elements per 16-byte vector
+  static constexpr int DY_VPP = DYC / VPL, X_VPP = XC / VPL;  // vectors per pixel
+  static constexpr int DY_NV = (32 * DY_VPP + 63) / 64, X_NV = (XR * XW * X_VPP + 63) / 64;  // vectors per lane
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rs, int k0, int c0, int lane) {
+  // operand fragment of v_mfma_f32_16x16x32_bf16 from a [pixel][channel] LDS tile: lane l gets channel c0+(l&15),
+  // pixels k0 + 8*(l>>4) + 0..7.  Two transposed 4x16 block reads (cdna guide T10): lane i = 4q+p of a 16-lane
+  // group supplies the address of block row q, columns 4p..4p+3.
+  const int i = lane & 15, g = lane >> 4;
+  const char* p0 = tile + (k0 + 8 * g + (i >> 2)) * rs + (c0 + 4 * (i & 3)) * 2;
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * rs));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <typename T, int KS, int CT, int IT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
+  using C = WgradCfg<T, KS, CT, IT>;
+  constexpr int ES = C::ES, KK = C::KK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* dyt = smem + wave * C::WAVE_BYTES;
+  char* xt = dyt + C::DY_BYTES;
+  float* red = reinterpret_cast<float*>(smem + 4 * C::WAVE_BYTES);
+  float* redb = red + C::DYC * C::RED_RS;
+
+  const int ob = blockIdx.x * C::DYC, ib = blockIdx.y * C::XC;  // channel offsets of this block
+  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0);
+
+  f32x4 acc[CT][KK][IT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+      for (int it = 0; it < IT; ++it) acc[ct][t][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  uint4 rdy[C::DY_NV], rx[C::X_NV];
+
+  auto load_unit = [&](long long u) {
+    // pixel coordinates of the unit
+    int n = 0, y = 0, x0 = 0;
+    long long m0 = 0;
+    if (KS == 3) {
+      const int seg = (int)(u % a.SEG);
+      const long long r = u / a.SEG;
+      y = (int)(r % a.H);
+      n = (int)(r / a.H);
+      x0 = seg * 32;
+    } else {
+      m0 = u * 32;
+    }
+#pragma unroll
+    for (int k = 0; k < C::DY_NV; ++k) {
+      const int idx = lane + 64 * k;
+      const int p = idx / C::DY_VPP, v = idx - p * C::DY_VPP;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      const int c = ob + v * C::VPL;
+      bool ok = (idx < 32 * C::DY_VPP);
+      long long pix;
+      if (KS == 3) { ok = ok && (x0 + p < a.W); pix = ((long long)n * a.H + y) * a.W + x0 + p; }
+      else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
+      if (ok) {
+        const char* src = a.dy + (pix * a.dy_ps + c) * ES;
+        if (a.vec_ok && c + C::VPL <= a.Cout) {
+          val = *reinterpret_cast<const uint4*>(src);
+        } else {
+          T tmp[C::VPL];
+#pragma unroll
+          for (int e = 0; e < C::VPL; ++e) tmp[e] = (c + e < a.Cout) ? reinterpret_cast<const T*>(src)[e] : from_f32<T>(0.f);
+          val = *reinterpret_cast<const uint4*>(tmp);
+        }
+      }
+      rdy[k] = val;
+    }
+#pragma unroll
+    for (int k = 0; k < C::X_NV; ++k) {
+      const int idx = lane + 64 * k;
+      const int p = idx / C::X_VPP, v = idx - p * C::X_VPP;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      const int c = ib + v * C::VPL;
+      bool ok = (idx < C::XR * C::XW * C::X_VPP);
+      long long pix;
+      if (KS == 3) {
+        const int r = p / C::XW, col = p - r * C::XW;
+        const int yy = y + r - 1, xx = x0 + col - 1;
+        ok = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        pix = ((long long)n * a.H + yy) * a.W + xx;
+      } else {
+        ok = ok && (m0 + p < a.M);
+        pix = m0 + p;
+      }
+      if (ok) {
+        const char* src = a.x + (pix * a.x_ps + c) * ES;
+        if (a.vec_ok && c + C::VPL <= a.Cin) {
+          val = *reinterpret_cast<const uint4*>(src);
+        } else {
+          T tmp[C::VPL];
+#pragma unroll
+          for (int e = 0; e < C::VPL; ++e) tmp[e] = (c + e < a.Cin) ? reinterpret_cast<const T*>(src)[e] : from_f32<T>(0.f);
+          val = *reinterpret_cast<const uint4*>(tmp);
+        }
+      }
+      rx[k] = val;
+    }
+  };
+
+  auto store_unit = [&]() {
+#pragma unroll
+    for (int k = 0; k < C::DY_NV; ++k) {
+      const int idx = lane + 64 * k;
+      const int p = idx / C::DY_VPP, v = idx - p * C::DY_VPP;
+      if (idx < 32 * C::DY_VPP) *reinterpret_cast<uint4*>(dyt + p * C::DY_RS + v * 16) = rdy[k];
+    }
+#pragma unroll
+    for (int k = 0; k < C::X_NV; ++k) {
+      const int idx = lane + 64 * k;
+      const int p = idx / C::X_VPP, v = idx - p * C::X_VPP;
+      if (idx < C::XR * C::XW * C::X_VPP) *reinterpret_cast<uint4*>(xt + p * C::X_RS + v * 16) = rx[k];
+    }
+  };
+
+  long long u = u_lo + wave;
+  if (u < u_hi) load_unit(u);
+  while (u < u_hi) {
+    store_unit();
+    const long long un = u + 4;
+    if (un < u_hi) load_unit(un);
+    // wave-private tile: program order + the compiler's lgkmcnt waits are the only synchronisation needed
+    if constexpr (ES == 2) {
+      bf16x8 af[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, 0, ct * 16, lane);
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int ky = (KS == 3) ? t / 3 : 0, kx = (KS == 3) ? t % 3 : 0;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const bf16x8 bfg = tr_frag(xt + ky * C::XW * C::X_RS, C::X_RS, kx, it * 16, lane);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfg, acc[ct][t][it], 0, 0, 0);
+        }
+      }
+    } else {
+      const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float af[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const float*>(dyt + (4 * j + g) * C::DY_RS + (ct * 16 + l15) * 4);
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+          const int ky = (KS == 3) ? t / 3 : 0, kx = (KS == 3) ? t % 3 : 0;
+#pragma unroll
+          for (int it = 0; it < IT; ++it) {
+            const float bv = *reinterpret_cast<const float*>(xt + (ky * C::XW + 4 * j + g + kx) * C::X_RS + (it * 16 + l15) * 4);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct], bv, acc[ct][t][it], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (do_bias && lane < C::DYC) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int p = 0; p < 32; ++p) s += to_f32(*reinterpret_cast<const T*>(dyt + p * C::DY_RS + lane * ES));
+      bsum += s;
+    }
+    u = un;
+  }
+
+  // ---- cross-wave reduction in LDS, laid out [co][ci][tap] = OIHW order of this block
+  for (int i = tid; i < C::DYC * C::RED_RS + C::DYC; i += 256) red[i] = 0.f;
+  __syncthreads();
+  {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            atomicAdd(&red[(ct * 16 + 4 * g + r) * C::RED_RS + (it * 16 + l15) * KK + t], acc[ct][t][it][r]);
+    if (do_bias && lane < C::DYC) atomicAdd(&redb[lane], bsum);
+  }
+  __syncthreads();
+  constexpr int ROW = C::XC * KK;
+  for (int i = tid; i < C::DYC * ROW; i += 256) {
+    const int co = i / ROW, rem = i - co * ROW;
+    const int ci = rem / KK;
+    if (ob + co < a.Cout && ib + ci < a.Cin)
+      atomicAdd(&a.dW[((long long)(a.o0 + ob + co) * a.I_total + (a.i0 + ib)) * KK + rem], red[co * C::RED_RS + rem] * a.scale);
+  }
+  if (do_bias && tid < C::DYC && ob + tid < a.Cout) atomicAdd(&a.db[a.o0 + ob + tid], redb[tid] * a.scale);
+}
+
+template <typename T, int KS, int CT, int IT>
+int launch_wgrad(WgradK k, hipStream_t st) {
+  using C = WgradCfg<T, KS, CT, IT>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "wgrad LDS");
+  const int gx = cdiv(k.Cout, C::DYC), gy = cdiv(k.Cin, C::XC);
+  long long s = 1024 / ((long long)gx * gy);  // ~4 workgroups per CU in flight
+  if (s > k.U / 4) s = k.U / 4;
+  if (s < 1) s = 1;
+  if (s > 65535) s = 65535;
+  k.S = (int)s;
+  auto fn = conv_wgrad_kernel<T, KS, CT, IT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(gx, gy, k.S), dim3(256), C::LDS_BYTES, st, k);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_t x_ps, int Cin, const void* dy,
+                              int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
+                              void* stream) {
+  VMG_CHECK(ks == 1 || ks == 3, "conv_wgrad: ks must be 1 or 3");
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_wgrad: bad dtype");
+  VMG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
+  VMG_CHECK(x && dy && dW, "conv_wgrad: null pointer");
+  VMG_CHECK(x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad strides / slices");
+  const int es = dtype == VMG_BF16 ? 2 : 4, vpl = 16 / es;
+  WgradK k;
+  memset(&k, 0, sizeof(k));
+  k.x = (const char*)x; k.x_ps = x_ps; k.Cin = Cin; k.dy = (const char*)dy; k.dy_ps = dy_ps; k.Cout = Cout;
+  k.dW = dW; k.I_total = I_total; k.o0 = o0; k.i0 = i0; k.db = db; k.scale = scale;
+  k.N = N; k.H = H; k.W = W; k.M = (long long)N * H * W;
+  k.SEG = cdiv(W, 32);
+  k.U = ks == 3 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
+  k.vec_ok = ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (x_ps % vpl == 0) && (dy_ps % vpl == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
+  return ks == 3 ? launch_wgrad<float, 3, 3, 1>(k, st) : launch_wgrad<float, 1, 3, 3>(k, st);
+}

@@ -1,0 +1,336 @@
+// HBM-bound kernels of the path: LayerNorm (fwd/bwd), activation backward, depth<->space.  All are one pass
+// over the data with 16-byte vector accesses; statistics and parameter gradients are fp32.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct Vec {  // 16-byte vector of T
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+
+// ----------------------------------------------------------------------------------------- act backward
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ out, long long n,
+                               int act, float slope, float alpha) {
+  constexpr int V = Vec<T>::N;
+  const long long nv = n / V;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    Vec<T> a = reinterpret_cast<const Vec<T>*>(dy)[i];
+    Vec<T> r = reinterpret_cast<const Vec<T>*>(ref)[i];
+    Vec<T> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float u = to_f32(r.v[e]);
+      float d = 1.f;
+      if (act == VMG_ACT_RELU) d = u > 0.f ? 1.f : 0.f;
+      else if (act == VMG_ACT_LRELU) d = u > 0.f ? 1.f : slope;
+      else if (act == VMG_ACT_GELU) d = gelu_erf_grad(u);
+      o.v[e] = from_f32<T>(to_f32(a.v[e]) * d * alpha);
+    }
+    reinterpret_cast<Vec<T>*>(out)[i] = o;
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = nv * V; i < n; ++i) {
+      const float u = to_f32(ref[i]);
+      float d = 1.f;
+      if (act == VMG_ACT_RELU) d = u > 0.f ? 1.f : 0.f;
+      else if (act == VMG_ACT_LRELU) d = u > 0.f ? 1.f : slope;
+      else if (act == VMG_ACT_GELU) d = gelu_erf_grad(u);
+      out[i] = from_f32<T>(to_f32(dy[i]) * d * alpha);
+    }
+}
+
+// ----------------------------------------------------------------------------------------- depth <-> space
+// PixelShuffle(2) order (models/vmg.py:380): channel co = c*4 + i*2 + j  <->  pixel (2y+i, 2x+j), channel c.
+template <typename T, bool TO_DEPTH>
+__global__ void pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int c) {
+  // one thread per (low-res pixel, c): moves 4 elements
+  const long long total = (long long)N * H * W * c;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c);
+    long long p = i / c;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    const long long lo = (((long long)n * H + y) * W + x) * (4LL * c) + 4 * cc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long hi = (((long long)n * 2 * H + 2 * y + (r >> 1)) * (2 * W) + 2 * x + (r & 1)) * c + cc;
+      if (TO_DEPTH) out[lo + r] = in[hi];
+      else out[hi] = in[lo + r];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------- LayerNorm
+// One row per group of G lanes (G = 16, 32 or 64 chosen from C); each lane keeps its vectors in registers.
+constexpr int LN_MAXV = 4;  // vectors per lane -> C <= 64 * 4 * 8 = 2048 (bf16), 1024 (fp32)
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) VecN {
+  T v[V];
+};
+
+template <typename T, int V, int G>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, long long M,
+                                                            int C, float eps) {
+  const int nvec = C / V;
+  const int gl = threadIdx.x % G;
+  const long long groups_per_block = 256 / G;
+  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += (long long)gridDim.x * groups_per_block) {
+    const T* xr = x + row * C;
+    VecN<T, V> buf[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) {
+        buf[k] = reinterpret_cast<const VecN<T, V>*>(xr)[vi];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += to_f32(buf[k].v[e]);
+      }
+    }
+    const float mu = group_sum<G>(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float d = to_f32(buf[k].v[e]) - mu;
+          q += d * d;
+        }
+      }
+    }
+    const float rs = rsqrtf(group_sum<G>(q) / C + eps);
+    if (gl == 0 && mean) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    T* yr = y + row * C;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) {
+        VecN<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = vi * V + e;
+          o.v[e] = from_f32<T>((to_f32(buf[k].v[e]) - mu) * rs * w[c] + b[c]);
+        }
+        reinterpret_cast<VecN<T, V>*>(yr)[vi] = o;
+      }
+    }
+  }
+}
+
+template <typename T, int V, int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ w, T* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, long long M, int C) {
+  const int nvec = C / V;
+  const int gl = threadIdx.x % G;
+  const long long groups_per_block = 256 / G;
+  float pdw[LN_MAXV][V], pdb[LN_MAXV][V];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) pdw[k][e] = pdb[k][e] = 0.f;
+  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += (long long)gridDim.x * groups_per_block) {
+    const float mu = mean[row], rs = rstd[row];
+    VecN<T, V> bx[LN_MAXV], bg[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dy * w
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) {
+        bx[k] = reinterpret_cast<const VecN<T, V>*>(x + row * C)[vi];
+        bg[k] = reinterpret_cast<const VecN<T, V>*>(dy + row * C)[vi];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = vi * V + e;
+          const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
+          const float d = to_f32(bg[k].v[e]);
+          const float g = d * w[c];
+          s1 += g;
+          s2 += g * xh;
+          pdw[k][e] += d * xh;
+          pdb[k][e] += d;
+        }
+      }
+    }
+    s1 = group_sum<G>(s1) / C;
+    s2 = group_sum<G>(s2) / C;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) {
+        VecN<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int c = vi * V + e;
+          const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
+          const float g = to_f32(bg[k].v[e]) * w[c];
+          o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
+        }
+        reinterpret_cast<VecN<T, V>*>(dx + row * C)[vi] = o;
+      }
+    }
+  }
+  // parameter gradients: block-level sum in LDS, then one float atomic per channel per block
+  extern __shared__ float sm[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int vi = gl + k * G;
+    if (vi < nvec) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        atomicAdd(&sm[vi * V + e], pdw[k][e]);
+        atomicAdd(&sm[C + vi * V + e], pdb[k][e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(&dw[i], sm[i]);
+    atomicAdd(&db[i], sm[C + i]);
+  }
+}
+
+int ln_group(int nvec) { return nvec <= 16 ? 16 : (nvec <= 32 ? 32 : 64); }
+
+}  // namespace
+
+extern "C" int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
+                           void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "act_bwd: bad dtype");
+  VMG_CHECK(dy && ref && out && n > 0, "act_bwd: bad arguments");
+  VMG_CHECK(((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)out) % 16 == 0, "act_bwd: pointers must be 16-byte aligned");
+  const int blocks = (int)(cdiv64(n / 8 + 1, 256) > 2048 ? 2048 : cdiv64(n / 8 + 1, 256));
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)ref,
+                       (bf16*)out, (long long)n, act, slope, alpha);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)ref,
+                       (float*)out, (long long)n, act, slope, alpha);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "pixel_shuffle: bad dtype");
+  VMG_CHECK(in && out && N > 0 && H > 0 && W > 0 && c > 0, "pixel_shuffle: bad arguments");
+  const long long total = (long long)N * H * W * c;
+  const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16) {
+    if (to_depth) hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, N, H, W, c);
+    else hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, N, H, W, c);
+  } else {
+    if (to_depth) hipLaunchKernelGGL((pixel_shuffle_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W, c);
+    else hipLaunchKernelGGL((pixel_shuffle_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W, c);
+  }
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int V>
+static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, long long M, int C, float eps,
+                    hipStream_t st) {
+  const int nvec = C / V;
+  const int G = ln_group(nvec);
+  VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
+  const long long rows_per_block = 256 / G;
+  const int blocks = (int)(cdiv64(M, rows_per_block) > 8192 ? 8192 : cdiv64(M, rows_per_block));
+#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps)
+  if (G == 16) LN_LAUNCH(16);
+  else if (G == 32) LN_LAUNCH(32);
+  else LN_LAUNCH(64);
+#undef LN_LAUNCH
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int V>
+static int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
+                    long long M, int C, hipStream_t st) {
+  const int nvec = C / V;
+  const int G = ln_group(nvec);
+  VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
+  const long long rows_per_block = 256 / G;
+  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 1024 ? 1024 : cdiv64(M, rows_per_block * 8));
+  const int lds = 2 * C * 4;
+#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C)
+  if (G == 16) LN_LAUNCH(16);
+  else if (G == 32) LN_LAUNCH(32);
+  else LN_LAUNCH(64);
+#undef LN_LAUNCH
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+// widest vector (in elements) that divides C
+static int ln_vec(int dtype, int C) {
+  if (dtype == VMG_BF16) return C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1));
+  return C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);
+}
+
+extern "C" int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 int64_t M, int C, float eps, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_fwd: bad dtype");
+  VMG_CHECK(x && w && b && y && M > 0 && C > 0, "layernorm_fwd: bad arguments");
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "layernorm_fwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int v = ln_vec(dtype, C);
+  if (dtype == VMG_BF16) {
+    switch (v) {
+      case 8: return ln_fwd_t<bf16, 8>(x, w, b, y, mean, rstd, M, C, eps, st);
+      case 4: return ln_fwd_t<bf16, 4>(x, w, b, y, mean, rstd, M, C, eps, st);
+      case 2: return ln_fwd_t<bf16, 2>(x, w, b, y, mean, rstd, M, C, eps, st);
+      default: return ln_fwd_t<bf16, 1>(x, w, b, y, mean, rstd, M, C, eps, st);
+    }
+  }
+  switch (v) {
+    case 4: return ln_fwd_t<float, 4>(x, w, b, y, mean, rstd, M, C, eps, st);
+    case 2: return ln_fwd_t<float, 2>(x, w, b, y, mean, rstd, M, C, eps, st);
+    default: return ln_fwd_t<float, 1>(x, w, b, y, mean, rstd, M, C, eps, st);
+  }
+}
+
+extern "C" int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,
+                                 void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_bwd: bad dtype");
+  VMG_CHECK(dy && x && mean && rstd && w && dx && dw && db && M > 0 && C > 0, "layernorm_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int v = ln_vec(dtype, C);
+  if (dtype == VMG_BF16) {
+    switch (v) {
+      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+    }
+  }
+  switch (v) {
+    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
+  }
+}

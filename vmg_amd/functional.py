@@ -1,0 +1,388 @@
+"""torch.autograd.Function wrappers around the HIP kernels (forward and hand-written backward).
+
+PyTorch is the plumbing here (tensor storage, streams, the autograd graph); every contraction below runs in
+libvmg_hip.so.  Activations are channels-last (..., C); parameters stay fp32 in checkpoint layout and are packed
+(and cast to the compute dtype) on demand, cached per parameter version.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import hip
+from . import kernels as K
+from .hip import HipError
+
+# ---------------------------------------------------------------------------------------------------------
+# packed-weight cache: (id(param), kind, dtype, slices) -> (version, PackedConv)
+# ---------------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
+def _pad_to(n: int, m: int = 8) -> int:
+    return (n + m - 1) // m * m
+
+
+def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
+           i0: int = 0, on: Optional[int] = None) -> K.PackedConv:
+    """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
+    needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8)."""
+    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on)
+    ver = weight._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2] is weight:
+        return hit[1]
+    w = weight.detach()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    O, I = w.shape[0], w.shape[1]
+    if kind == "fwd":
+        if src_ch is None:
+            src_ch = [I]
+        if sum(src_ch) != I:
+            raise HipError(f"source channels {list(src_ch)} do not sum to weight input channels {I}")
+        if any(c % 8 for c in src_ch):
+            # zero-pad each slice of the K dimension to a multiple of 8 channels
+            parts, off = [], 0
+            for c in src_ch:
+                sl = w[:, off:off + c]
+                if c % 8:
+                    sl = torch.cat([sl, sl.new_zeros(O, _pad_to(c) - c, *w.shape[2:])], 1)
+                parts.append(sl)
+                off += c
+            w = torch.cat(parts, 1)
+            src_ch = [_pad_to(c) for c in src_ch]
+        pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch))
+    elif kind == "dgrad":
+        on = I - i0 if on is None else on
+        if O % 8:
+            w = torch.cat([w, w.new_zeros(_pad_to(O) - O, *w.shape[1:])], 0)
+        pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True)
+    else:
+        raise HipError(kind)
+    _PACK_CACHE[key] = (ver, pw, weight)
+    return pw
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
+def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    c = t.shape[-1]
+    if c % mult == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, _pad_to(c, mult) - c))
+
+
+def _act_grad(dy: torch.Tensor, y: Optional[torch.Tensor], pre: Optional[torch.Tensor], act: int, slope: float, alpha: float):
+    """d(out)/d(pre) applied to dy for out = act(pre) * alpha."""
+    if act == hip.ACT_NONE:
+        return dy if alpha == 1.0 else dy * alpha
+    return K.act_backward(dy, pre if act == hip.ACT_GELU else y, act, slope, alpha)
+
+
+class _Conv2d(torch.autograd.Function):
+    """out = [res +] alpha * act(conv(cat(srcs)) + bias), optional PixelShuffle(2) store."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, res, cfg, *srcs):
+        ks, act, slope, alpha, pixel_shuffle, N, H, W = cfg
+        dt = srcs[0].dtype
+        src_ch = [s.shape[-1] for s in srcs]
+        srcs_p = [_pad_channels(s) for s in srcs]
+        pw = packed(weight, dt, "fwd", src_ch)
+        need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
+        out, pre = K.conv_forward(srcs_p, pw, bias, N, H, W, act=act, slope=slope, alpha=alpha, res=res,
+                                  pixel_shuffle=pixel_shuffle, want_pre=need_pre)
+        ctx.cfg = cfg
+        ctx.src_ch = src_ch
+        ctx.has_res = res is not None
+        ctx.has_bias = bias is not None
+        # relu / lrelu derivatives come from the sign of the output (taken before the residual is added, so keep
+        # the sign information only when there is no residual; with a residual the activation is NONE on this path)
+        if act in (hip.ACT_RELU, hip.ACT_LRELU) and res is not None:
+            raise HipError("activation + residual in one epilogue is not differentiable from the output alone")
+        ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre, *srcs_p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ks, act, slope, alpha, pixel_shuffle, N, H, W = ctx.cfg
+        weight, y, pre = ctx.saved_tensors[:3]
+        srcs_p = ctx.saved_tensors[3:]
+        dy = dy.contiguous()
+        d_res = dy if ctx.has_res else None
+        if pixel_shuffle:
+            # undo the depth-to-space on the gradient (and on y for the activation derivative)
+            dy = K.pixel_unshuffle(dy, N, H, W)
+            y = K.pixel_unshuffle(y, N, H, W) if y is not None else None
+        dpre = _act_grad(dy, y, pre, act, slope, alpha)
+        O = weight.shape[0]
+        I = weight.shape[1]
+        d_w = d_b = None
+        d_srcs: List[Optional[torch.Tensor]] = []
+        off = 0
+        dpre_p = _pad_channels(dpre)
+        for i, c in enumerate(ctx.src_ch):
+            if ctx.needs_input_grad[4 + i]:
+                pw = packed(weight, dpre.dtype, "dgrad", None, off, c)
+                dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W)
+                d_srcs.append(dx)
+            else:
+                d_srcs.append(None)
+            off += c
+        if ctx.needs_input_grad[0]:
+            d_w = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+            d_b = torch.zeros(O, dtype=torch.float32, device=weight.device) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+            off = 0
+            for i, c in enumerate(ctx.src_ch):
+                K.conv_wgrad(srcs_p[i][..., :c] if srcs_p[i].shape[-1] != c else srcs_p[i], dpre, d_w, d_b if i == 0 else None,
+                             ks, N, H, W, i0=off)
+                off += c
+        elif ctx.has_bias and ctx.needs_input_grad[1]:
+            d_b = dpre.float().reshape(-1, O).sum(0)
+        return (d_w, d_b, d_res, None, *d_srcs)
+
+
+def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int,
+           ks: int = 3, act: int = hip.ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
+           pixel_shuffle: bool = False) -> torch.Tensor:
+    """Channels-last convolution / linear over N*H*W pixels; srcs are virtually concatenated along channels."""
+    cfg = (ks, act, float(slope), float(alpha), bool(pixel_shuffle), int(N), int(H), int(W))
+    return _Conv2d.apply(weight, bias, res, cfg, *srcs)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = hip.ACT_NONE, alpha: float = 1.0,
+           res: Optional[torch.Tensor] = None, slope: float = 0.0) -> torch.Tensor:
+    """y[..., O] = act(x[..., I] @ W^T + b) * alpha (+ res): the KS = 1 convolution on (M, C) rows."""
+    M = x.numel() // x.shape[-1]
+    out = conv2d([x], weight, bias, 1, 1, M, ks=1, act=act, slope=slope, alpha=alpha,
+                 res=None if res is None else res)
+    return out.reshape(*x.shape[:-1], weight.shape[0])
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_forward(x, w, b, eps)
+        ctx.save_for_backward(x, mean, rstd, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w = ctx.saved_tensors
+        dx, dw, db = K.layernorm_backward(dy, x, mean, rstd, w)
+        return dx, dw, db, None
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """nn.LayerNorm over the last (channel) dimension."""
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+# =========================================================================================================
+# Ops still expressed with PyTorch-ROCm device ops (autograd by torch).  Each is HBM-bound index / elementwise
+# work around the MFMA kernels above and is replaced by a hand-written HIP kernel as the rounds proceed; the
+# table in DESIGN.md ("what runs where") is kept in step with this section.  None of them runs on the CPU.
+# =========================================================================================================
+import math
+
+import torch.nn.functional as F
+
+
+def morph_tokens(x: torch.Tensor, axis: str, chunk: int, Cp: int) -> torch.Tensor:
+    """Token layout of the H-/W-branch (models/function.py:763-764, 776-777): pad C->Cp and the mixed axis to a
+    multiple of `chunk`; token (group, k) gets features f = p*S + s <- x[position p of the group, channel k*S + s]."""
+    B, T, H, W, C = x.shape
+    S = Cp // chunk
+    if axis == "h":
+        Hp = int(math.ceil(H / chunk)) * chunk
+        xp = F.pad(x, (0, Cp - C, 0, 0, 0, Hp - H)).transpose(2, 3)
+        L = W * Hp
+    else:
+        Wp = int(math.ceil(W / chunk)) * chunk
+        xp = F.pad(x, (0, Cp - C, 0, Wp - W))
+        L = H * Wp
+    t = xp.reshape(B, T, L // chunk, chunk, chunk, S)
+    return t.permute(0, 1, 2, 4, 3, 5).reshape(B, T, L // chunk, chunk, chunk * S).contiguous()
+
+
+def morph_untokens(t: torch.Tensor, axis: str, chunk: int, Cp: int, H: int, W: int, C: int) -> torch.Tensor:
+    """Inverse layout + crop (models/function.py:772, 785)."""
+    B, T, G = t.shape[:3]
+    S = Cp // chunk
+    u = t.reshape(B, T, G, chunk, chunk, S).permute(0, 1, 2, 4, 3, 5)
+    if axis == "h":
+        Hp = int(math.ceil(H / chunk)) * chunk
+        return u.reshape(B, T, W, Hp, Cp).transpose(2, 3)[..., 0:H, :, :C].contiguous()
+    Wp = int(math.ceil(W / chunk)) * chunk
+    return u.reshape(B, T, H, Wp, Cp)[..., 0:W, :C].contiguous()
+
+
+def channel_attention_residual(r, x, w1, b1, w2, b2, out_scale: float):
+    """(r * sigmoid(W2 relu(W1 GAP(r) + b1) + b2) + x) * out_scale on (N,H,W,C) (models/function.py:555-558, 581)."""
+    g = r.float().mean((1, 2))
+    g = F.relu(F.linear(g, w1.flatten(1), b1))
+    g = torch.sigmoid(F.linear(g, w2.flatten(1), b2)).to(r.dtype)
+    return (r * g[:, None, None, :] + x) * out_scale
+
+
+def reweight_mix(h, w, c, fc1w, fc1b, fc2w, fc2b):
+    """softmax re-weighting of the three branches (models/function.py:791-793): a = Mlp(mean_{T,H,W}(h+w+c))."""
+    B, C = h.shape[0], h.shape[-1]
+    a = (h.float() + w.float() + c.float()).mean((1, 2, 3))
+    a = F.linear(F.gelu(F.linear(a, fc1w, fc1b)), fc2w, fc2b).reshape(B, C, 3).softmax(-1).to(h.dtype)
+    a = a[:, None, None, None]
+    return h * a[..., 0] + w * a[..., 1] + c * a[..., 2]
+
+
+def tanh_gate(x, y):
+    """(x + y) * tanh(y) (models/function.py:801-802)."""
+    return (x + y) * torch.tanh(y)
+
+
+def identity_grid(n: int, h: int, w: int, device) -> torch.Tensor:
+    ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    return torch.stack([xs, ys], 0).float()[None].expand(n, -1, -1, -1).contiguous()
+
+
+def _norm_grid(g, h, w):
+    gx = 2.0 * g[..., 0] / max(w - 1, 1) - 1.0
+    gy = 2.0 * g[..., 1] / max(h - 1, 1) - 1.0
+    return torch.stack((gx, gy), -1)
+
+
+def grid_sample_flow(x: torch.Tensor, flow: torch.Tensor, mode: str, padding: str) -> torch.Tensor:
+    """Channels-last flow warp: x (n,h,w,c), flow (n,h,w,2) fp32 pixel offsets (models/trajectory.py:95-116)."""
+    n, h, w, c = x.shape
+    ys, xs = torch.meshgrid(torch.arange(h, device=x.device), torch.arange(w, device=x.device), indexing="ij")
+    grid = _norm_grid(torch.stack((xs, ys), 2).float() + flow, h, w)
+    o = F.grid_sample(x.permute(0, 3, 1, 2), grid.to(x.dtype), mode=mode, padding_mode=padding, align_corners=True)
+    return o.permute(0, 2, 3, 1).contiguous()
+
+
+def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+    """Advect the tracked-location maps (n,2k,h,w) with nearest sampling, border padding (trajectory.py:332-333)."""
+    n, k2, h, w = loc.shape
+    ys, xs = torch.meshgrid(torch.arange(h, device=loc.device), torch.arange(w, device=loc.device), indexing="ij")
+    grid = _norm_grid(torch.stack((xs, ys), 2).float() + flow, h, w)
+    return F.grid_sample(loc, grid, mode="nearest", padding_mode="border", align_corners=True)
+
+
+def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):
+    """LTAM_multi_head.forward_wins without the output projection (models/trajectory.py:683-774)."""
+    n, h, w, c = q.shape
+    t = len(keys)
+    d = c // heads
+    g = loc.reshape(n, t, 2, h, w).permute(0, 1, 3, 4, 2)
+    grid = _norm_grid(g, h, w).reshape(n * t, h, w, 2)
+
+    def gather(lst):
+        src = torch.stack(lst, 1).reshape(n * t, h, w, c).permute(0, 3, 1, 2)
+        o = F.grid_sample(src, grid.to(src.dtype), mode="nearest", padding_mode="zeros", align_corners=True)
+        return o.permute(0, 2, 3, 1).reshape(n, t, h, w, c)
+
+    v = gather(vals)
+    k = F.normalize(gather(keys).float(), dim=-1)
+    qn = F.normalize(q.float(), dim=-1)
+
+    def windows(z):
+        if z.dim() == 4:
+            z = z[:, None]
+        tt = z.shape[1]
+        z = z.reshape(n, tt, h // wh, wh, w // ww, ww, heads, d)
+        return z.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(n, (h // wh) * (w // ww), heads, tt * wh * ww, d)
+
+    qw, kw, vw = windows(qn), windows(k), windows(v.float())
+    pw = [decay_v.clone()]
+    for _ in range(1, t):
+        pw.append(pw[-1] * decay_v)
+    pw = torch.stack(pw[::-1], 1)  # (head, t): key-frame j (0 = oldest) -> decay^(t-j)
+    qn_ = wh * ww
+    pe = (pw[:, None, :, None] * rpe[:, :, None, :]).reshape(heads, qn_, t * qn_)
+    logits = torch.matmul(qw * scale, kw.transpose(-1, -2)) + pe[None, None]
+    out = torch.matmul(logits.softmax(-1), vw)
+    out = out.reshape(n, h // wh, w // ww, heads, wh, ww, d).permute(0, 1, 4, 2, 5, 3, 6).reshape(n, h, w, c)
+    return out.to(q.dtype).contiguous()
+
+
+def space_to_depth(x: torch.Tensor) -> torch.Tensor:
+    """'n d c (h neih) (w neiw) -> n d h w (neiw neih c)' on channels-last features (models/layers.py:785)."""
+    B, T, H, W, C = x.shape
+    return x.reshape(B, T, H // 2, 2, W // 2, 2, C).permute(0, 1, 2, 4, 5, 3, 6).reshape(B, T, H // 2, W // 2, 4 * C).contiguous()
+
+
+def depth_to_space(x: torch.Tensor) -> torch.Tensor:
+    """'n d (neiw neih c) h w -> n d (h neih) (w neiw) c' (models/layers.py:790)."""
+    B, T, H, W, C = x.shape
+    c4 = C // 4
+    return x.reshape(B, T, H, W, 2, 2, c4).permute(0, 1, 2, 5, 3, 4, 6).reshape(B, T, 2 * H, 2 * W, c4).contiguous()
+
+
+# ---- 3-D shifted windows (models/swin_3d.py) ----------------------------------------------------------
+def window_partition(y: torch.Tensor, ws, ss, pads):
+    """zero-pad (D,H,W) by pads, roll by -ss, cut into (wt,wh,ww) windows -> (B*nW, N, C) (swin_3d.py:55-68, 786-797)."""
+    B, D, H, W, C = y.shape
+    pd, pb, pr = pads
+    y = F.pad(y, (0, 0, 0, pr, 0, pb, 0, pd))
+    _, Dp, Hp, Wp, _ = y.shape
+    if any(s > 0 for s in ss):
+        y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    yw = y.reshape(B, Dp // ws[0], ws[0], Hp // ws[1], ws[1], Wp // ws[2], ws[2], C)
+    yw = yw.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, ws[0] * ws[1] * ws[2], C).contiguous()
+    return yw, (B, D, H, W, Dp, Hp, Wp, tuple(ws), tuple(ss))
+
+
+def window_reverse(aw: torch.Tensor, meta) -> torch.Tensor:
+    B, D, H, W, Dp, Hp, Wp, ws, ss = meta
+    y = aw.reshape(B, Dp // ws[0], Hp // ws[1], Wp // ws[2], ws[0], ws[1], ws[2], -1)
+    y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, Dp, Hp, Wp, -1)
+    if any(s > 0 for s in ss):
+        y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
+    return y[:, :D, :H, :W].contiguous()
+
+
+def shift_mask(D, H, W, ws, ss, device) -> torch.Tensor:
+    """(nW, N, N) of 0 / -100 (swin_3d.py:104-118)."""
+    img = torch.zeros(1, D, H, W, 1, device=device)
+    cnt = 0
+    for d in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
+        for h in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
+            for w in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
+                img[:, d, h, w, :] = cnt
+                cnt += 1
+    mw, _ = window_partition(img, ws, (0, 0, 0), (0, 0, 0))
+    mw = mw.squeeze(-1)
+    diff = mw[:, None, :] - mw[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+
+def window_cross_slice_attention(q, kv, table, index, mask, heads: int, ws_cfg):
+    """rWindowAttention.attention for every time slice of the window (swin_3d.py:167-252): queries of slice i
+    attend to the N - interval tokens of the other slices; bias gathered from the relative-position table."""
+    B_, N, C = q.shape
+    d = C // heads
+    scale = d ** -0.5
+    interval = ws_cfg[1] * ws_cfg[2]
+    total = ws_cfg[0] * interval
+    qh = q.reshape(B_, N, heads, d).permute(0, 2, 1, 3).float()
+    kvh = kv.reshape(B_, N, 2, heads, d).permute(2, 0, 3, 1, 4).float()
+    k, v = kvh[0], kvh[1]
+    nsl = len(range(0, total, interval))
+    outs = []
+    for i in range(nsl):
+        lo = i * interval
+        hi = total if i == nsl - 1 else (i + 1) * interval
+        other = [s for s in range(total) if s < lo or s >= hi]
+        attn = (qh[:, :, lo:hi] * scale) @ k[:, :, other].transpose(-2, -1)
+        bias = table[index[lo:hi][:, other].reshape(-1)].reshape(hi - lo, len(other), heads).permute(2, 0, 1)
+        attn = attn + bias[None]
+        if mask is not None:
+            nW = mask.shape[0]
+            attn = attn.reshape(B_ // nW, nW, heads, hi - lo, len(other)) + mask[:, lo:hi][:, :, other][None, :, None]
+            attn = attn.reshape(-1, heads, hi - lo, len(other))
+        outs.append((attn.softmax(-1) @ v[:, :, other]).transpose(1, 2).reshape(B_, hi - lo, C))
+    return torch.cat(outs, 1).to(q.dtype).contiguous()

@@ -48,6 +48,12 @@ SIGNATURES = {
     "vmg_conv_pack": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                               c_int, c_int, c_void_p, c_void_p]),
     "vmg_conv_fwd": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "vmg_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_void_p]),
+    "vmg_pixel_shuffle": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_layernorm_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "vmg_layernorm_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vmg_conv_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
+                               c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
 }
 
 

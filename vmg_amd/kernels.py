@@ -155,3 +155,89 @@ def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[to
     d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt = act, slope, alpha, actgrad, int(pixel_shuffle), mt
     hip.check(hip.lib().vmg_conv_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_conv_fwd")
     return out, out_pre
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], ks: int, N: int, H: int,
+               W: int, scale: float = 1.0, o0: int = 0, i0: int = 0):
+    """dW (fp32, (O_total, I_total, ks, ks) or (O_total, I_total)) += scale * wgrad(x, dy); db += scale * sum(dy).
+    x (..., Cin) and dy (..., Cout) are channels-last tensors over the same N*H*W pixels (channel slices allowed)."""
+    hip.require_cuda(x, dy, dW, db)
+    if dW.dtype != torch.float32 or not dW.is_contiguous() or (db is not None and (db.dtype != torch.float32 or not db.is_contiguous())):
+        raise HipError("parameter gradients must be contiguous fp32")
+    if x.dtype != dy.dtype:
+        raise HipError("x and dy must share a dtype")
+    M = N * H * W
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    if x.numel() // Cin != M or dy.numel() // Cout != M:
+        raise HipError("x / dy do not cover N*H*W pixels")
+    O_total, I_total = dW.shape[0], dW.shape[1]
+    kk = 1 if dW.dim() == 2 else dW.shape[2]
+    if kk != ks or o0 + Cout > O_total or i0 + Cin > I_total or (db is not None and db.numel() != O_total):
+        raise HipError(f"gradient tensor {tuple(dW.shape)} does not match conv (ks={ks}, Cout={Cout}+{o0}, Cin={Cin}+{i0})")
+    hip.check(hip.lib().vmg_conv_wgrad(hip.dtype_code(x.dtype), ks, N, H, W, x.data_ptr(), _pix_stride(x), Cin, dy.data_ptr(),
+                                       _pix_stride(dy), Cout, dW.data_ptr(), I_total, o0, i0,
+                                       db.data_ptr() if db is not None else None, scale, hip.stream_ptr()), "vmg_conv_wgrad")
+
+
+def act_backward(dy: torch.Tensor, ref: torch.Tensor, act: int, slope: float, alpha: float) -> torch.Tensor:
+    """dy * alpha * act'(ref); ref = activation output (RELU/LRELU) or pre-activation (GELU)."""
+    hip.require_cuda(dy, ref)
+    if dy.shape != ref.shape or dy.dtype != ref.dtype or not dy.is_contiguous() or not ref.is_contiguous():
+        raise HipError("act_backward: dy / ref must be contiguous tensors of one shape and dtype")
+    out = torch.empty_like(dy)
+    hip.check(hip.lib().vmg_act_bwd(hip.dtype_code(dy.dtype), dy.data_ptr(), ref.data_ptr(), out.data_ptr(), dy.numel(), act, slope,
+                                    alpha, hip.stream_ptr()), "vmg_act_bwd")
+    return out
+
+
+def pixel_shuffle(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+    """(N,H,W,4c) -> (N,2H,2W,c), torch PixelShuffle(2) order."""
+    hip.require_cuda(x)
+    c4 = x.shape[-1]
+    if c4 % 4 or x.numel() != N * H * W * c4 or not x.is_contiguous():
+        raise HipError("pixel_shuffle: bad input")
+    out = torch.empty((N, 2 * H, 2 * W, c4 // 4), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().vmg_pixel_shuffle(hip.dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), N, H, W, c4 // 4, 0, hip.stream_ptr()),
+              "vmg_pixel_shuffle")
+    return out
+
+
+def pixel_unshuffle(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+    """(N,2H,2W,c) -> (N,H,W,4c): inverse of pixel_shuffle."""
+    hip.require_cuda(x)
+    c = x.shape[-1]
+    if x.numel() != N * 4 * H * W * c or not x.is_contiguous():
+        raise HipError("pixel_unshuffle: bad input")
+    out = torch.empty((N, H, W, 4 * c), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().vmg_pixel_shuffle(hip.dtype_code(x.dtype), x.data_ptr(), out.data_ptr(), N, H, W, c, 1, hip.stream_ptr()),
+              "vmg_pixel_shuffle")
+    return out
+
+
+def layernorm_forward(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5, want_stats: bool = True):
+    hip.require_cuda(x, w, b)
+    C = x.shape[-1]
+    if not x.is_contiguous() or w.dtype != torch.float32 or b.dtype != torch.float32 or w.numel() != C or b.numel() != C:
+        raise HipError("layernorm: x must be contiguous, w/b fp32 of length C")
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if want_stats else None
+    hip.check(hip.lib().vmg_layernorm_fwd(hip.dtype_code(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                          mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None,
+                                          M, C, eps, hip.stream_ptr()), "vmg_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor):
+    hip.require_cuda(dy, x, mean, rstd, w)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().vmg_layernorm_bwd(hip.dtype_code(x.dtype), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
+              "vmg_layernorm_bwd")
+    return dx, dw, db

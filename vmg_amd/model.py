@@ -1,0 +1,739 @@
+"""VMG network with the reference's nn.Module surface (models/vmg.py:176-637) over the HIP kernels.
+
+Drop-in contract: same constructor keywords, same attribute names read by the reference's
+Trainer/Tester (``spynet``, ``mlp_wd_param``, ``num_out_frames``), same state-dict keys / shapes / layouts (conv
+OIHW, Linear (out,in), buffers gamma_h/gamma_w/decay_v/relative_position_index/spynet.mean/std), same call
+``module(x, flow_pretrained=None, config_amp=None)`` with x (B,T,3,H,W) -> (B,T,3,4H,4W).
+
+MI355X-first differences from the reference's Python (none change results):
+  * features live channels-last (B*T, H, W, C) end to end: no NCHW<->NHWC round trips around every conv;
+  * every convolution / Linear is the MFMA implicit-GEMM kernel with bias, activation, residual, scale and
+    PixelShuffle fused in its epilogue; channel concats are virtual (several source pointers);
+  * nn.Conv2d / nn.Linear / nn.LayerNorm objects below are PARAMETER HOLDERS (they give identical state-dict
+    keys and initialisation); their own forward() is never used on the hot path.
+
+There is no CPU path: calling the module on CPU tensors raises (vmg_amd.hip.HipError).
+"""
+from __future__ import annotations
+
+import math
+from fractions import Fraction
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as FH
+from . import hip
+from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, HipError
+
+
+# ---------------------------------------------------------------------------------------------------------
+# small helpers
+# ---------------------------------------------------------------------------------------------------------
+def _drop_path(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """timm DropPath semantics: per-sample Bernoulli(1-p) mask scaled by 1/(1-p) (models/function.py:1210)."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return x * mask
+
+
+def conv(mod: nn.Conv2d, srcs: Sequence[torch.Tensor], N: int, H: int, W: int, **kw) -> torch.Tensor:
+    return FH.conv2d(srcs, mod.weight, mod.bias, N, H, W, ks=mod.kernel_size[0], **kw)
+
+
+def lin(mod: nn.Linear, x: torch.Tensor, **kw) -> torch.Tensor:
+    return FH.linear(x, mod.weight, mod.bias, **kw)
+
+
+def lnorm(mod: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    return FH.layer_norm(x, mod.weight, mod.bias, mod.eps)
+
+
+def flow_warp_nhwc(x: torch.Tensor, flow: torch.Tensor, mode: str = "bilinear", padding: str = "zeros") -> torch.Tensor:
+    """x (n,h,w,c) sampled at pixel grid + flow (n,h,w,2), align_corners=True (models/trajectory.py:71-116)."""
+    n, h, w, c = x.shape
+    if (h, w) != tuple(flow.shape[1:3]):
+        raise ValueError(f"The spatial sizes of input ({(h, w)}) and flow ({tuple(flow.shape[1:3])}) are not the same.")
+    return FH.grid_sample_flow(x, flow, mode, padding)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SPyNet (models/vmg.py:18-173).  2-4 % of the FLOPs; stays on PyTorch-ROCm ops this round.
+# ---------------------------------------------------------------------------------------------------------
+class _ConvModule(nn.Module):
+    def __init__(self, cin, cout, act):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 7, 1, 3)
+        self.act = act
+
+    def forward(self, x):
+        x = self.conv(x)
+        return F.relu(x) if self.act else x
+
+
+class SPyNetBasicModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.basic_module = nn.Sequential(_ConvModule(8, 32, True), _ConvModule(32, 64, True), _ConvModule(64, 32, True),
+                                          _ConvModule(32, 16, True), _ConvModule(16, 2, False))
+
+    def forward(self, x):
+        return self.basic_module(x)
+
+
+def _warp_nchw(x, flow_nhw2, padding):
+    n, c, h, w = x.shape
+    ys, xs = torch.meshgrid(torch.arange(h, device=x.device), torch.arange(w, device=x.device), indexing="ij")
+    g = torch.stack((xs, ys), 2).to(x.dtype) + flow_nhw2
+    gx = 2.0 * g[..., 0] / max(w - 1, 1) - 1.0
+    gy = 2.0 * g[..., 1] / max(h - 1, 1) - 1.0
+    return F.grid_sample(x, torch.stack((gx, gy), 3), mode="bilinear", padding_mode=padding, align_corners=True)
+
+
+class SPyNet(nn.Module):
+    def __init__(self, pretrained=None):
+        super().__init__()
+        self.basic_module = nn.ModuleList([SPyNetBasicModule() for _ in range(6)])
+        if isinstance(pretrained, str):
+            import os
+            if os.path.isfile(pretrained):
+                sd = torch.load(pretrained, map_location="cpu")
+                self.load_state_dict(sd.get("state_dict", sd), strict=True)
+            else:
+                import warnings
+                warnings.warn(f"SPyNet weights '{pretrained}' are not a local file (no network here): keeping random init")
+        elif pretrained is not None:
+            raise TypeError(f"[pretrained] should be str or None, but got {type(pretrained)}.")
+        self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def compute_flow(self, ref, supp):
+        n, _, h, w = ref.size()
+        ref = [(ref - self.mean) / self.std]
+        supp = [(supp - self.mean) / self.std]
+        for _ in range(5):
+            ref.append(F.avg_pool2d(ref[-1], 2, 2, count_include_pad=False))
+            supp.append(F.avg_pool2d(supp[-1], 2, 2, count_include_pad=False))
+        ref, supp = ref[::-1], supp[::-1]
+        flow = ref[0].new_zeros(n, 2, h // 32, w // 32)
+        for level in range(6):
+            up = flow if level == 0 else F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+            warped = _warp_nchw(supp[level], up.permute(0, 2, 3, 1), "border")
+            flow = up + self.basic_module[level](torch.cat([ref[level], warped, up], 1))
+        return flow
+
+    def forward(self, ref, supp):
+        h, w = ref.shape[2:4]
+        w_up = w if (w % 32) == 0 else 32 * (w // 32 + 1)
+        h_up = h if (h % 32) == 0 else 32 * (h // 32 + 1)
+        ref = F.interpolate(ref, size=(h_up, w_up), mode="bilinear", align_corners=False)
+        supp = F.interpolate(supp, size=(h_up, w_up), mode="bilinear", align_corners=False)
+        flow = F.interpolate(self.compute_flow(ref, supp), size=(h, w), mode="bilinear", align_corners=False)
+        return torch.stack((flow[:, 0] * (float(w) / float(w_up)), flow[:, 1] * (float(h) / float(h_up))), 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TAB block (models/function.py)
+# ---------------------------------------------------------------------------------------------------------
+class _CALayer(nn.Module):
+    def __init__(self, channel, reduction):
+        super().__init__()
+        self.conv_du = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1), nn.ReLU(), nn.Conv2d(channel // reduction, channel, 1),
+                                     nn.Sigmoid())
+
+
+class RCAB(nn.Module):
+    """conv3x3+ReLU, conv3x3, channel attention, + input (models/function.py:561-583, 542-558)."""
+
+    def __init__(self, n_feat, reduction=8):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat, 3, 1, 1), nn.ReLU(), nn.Conv2d(n_feat, n_feat, 3, 1, 1),
+                                  _CALayer(n_feat, reduction))
+
+    def forward(self, x, out_scale: float = 1.0):
+        B, T, H, W, C = x.shape
+        N = B * T
+        r = conv(self.body[0], [x], N, H, W, act=ACT_RELU)
+        r = conv(self.body[2], [r], N, H, W)
+        du = self.body[3].conv_du
+        return FH.channel_attention_residual(r, x.reshape(N, H, W, C), du[0].weight, du[0].bias, du[2].weight, du[2].bias,
+                                             out_scale).reshape(B, T, H, W, C)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        return lin(self.fc2, lin(self.fc1, x, act=ACT_GELU))
+
+
+class Mlp_cnn(nn.Module):
+    """conv3x3(C->rC, groups)+GELU then Linear(rC->C) (models/function.py:50-79)."""
+
+    def __init__(self, in_features, exp_r=4, n_groups=1):
+        super().__init__()
+        self.hidden_features = int(in_features * exp_r)
+        self.n_groups = n_groups
+        self.fc1 = nn.Conv2d(in_features, self.hidden_features, 3, 1, 1, groups=n_groups)
+        self.fc2 = nn.Linear(self.hidden_features, in_features)
+
+    def forward(self, x, res=None):
+        B, T, H, W, C = x.shape
+        N = B * T
+        if self.n_groups == 1:
+            h = conv(self.fc1, [x], N, H, W, act=ACT_GELU)
+        else:
+            G, cg, og = self.n_groups, C // self.n_groups, self.hidden_features // self.n_groups
+            parts = [FH.conv2d([x[..., g * cg:(g + 1) * cg]], self.fc1.weight[g * og:(g + 1) * og], self.fc1.bias[g * og:(g + 1) * og],
+                               N, H, W, ks=3, act=ACT_GELU) for g in range(G)]
+            h = torch.cat(parts, -1)
+        return lin(self.fc2, h, res=res).reshape(B, T, H, W, C)
+
+
+class Enhanced_MorphFCs_decay(nn.Module):
+    """Token mixer: H-, W- and channel-branch, softmax re-weighting, projection, tanh gate
+    (models/function.py:596-805).  STATEFUL like the reference: mlp_h/mlp_w weights are multiplied by
+    gamma_h/gamma_w in place on every forward call (SURVEY trap T1)."""
+
+    def __init__(self, dim, chunk_h=8, chunk_w=8, qkv_bias=False, channel_mixer="rcab"):
+        super().__init__()
+        self.chunk_h, self.chunk_w = chunk_h, chunk_w
+        self.Ch = int(np.ceil(dim / chunk_h)) * chunk_h
+        self.Cw = int(np.ceil(dim / chunk_w)) * chunk_w
+        self.mlp_h = nn.Sequential(nn.Linear(self.Ch, self.Ch, bias=qkv_bias), nn.ReLU())
+        self.mlp_w = nn.Sequential(nn.Linear(self.Cw, self.Cw, bias=qkv_bias), nn.ReLU())
+        if channel_mixer != "rcab":
+            raise NotImplementedError("channel_mixer must be 'rcab' (the only value a self-consistent shipped config uses)")
+        self.mlp_c = RCAB(n_feat=dim)
+        self.reweight = Mlp(dim, dim // 4, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.register_buffer("gamma_h", decay_gamma(chunk_h, self.Ch))
+        self.register_buffer("gamma_w", decay_gamma(chunk_w, self.Cw))
+
+    def forward(self, x):
+        B, T, H, W, C = x.shape
+        with torch.no_grad():  # T1: persistent, outside autograd, before the GEMM (function.py:766-768, 779-781)
+            self.mlp_h[0].weight.mul_(self.gamma_h)
+            self.mlp_w[0].weight.mul_(self.gamma_w)
+        th = FH.morph_tokens(x, "h", self.chunk_h, self.Ch)
+        th = lin(self.mlp_h[0], th, act=ACT_RELU, alpha=1.0 / self.Ch)
+        h = FH.morph_untokens(th, "h", self.chunk_h, self.Ch, H, W, C)
+        tw = FH.morph_tokens(x, "w", self.chunk_w, self.Cw)
+        tw = lin(self.mlp_w[0], tw, act=ACT_RELU, alpha=1.0 / self.Cw)
+        w = FH.morph_untokens(tw, "w", self.chunk_w, self.Cw, H, W, C)
+        c = self.mlp_c(x, out_scale=1.0 / C)
+        rw = self.reweight
+        y = FH.reweight_mix(h, w, c, rw.fc1.weight, rw.fc1.bias, rw.fc2.weight, rw.fc2.bias)
+        y = lin(self.proj, y)
+        return FH.tanh_gate(x, y)
+
+
+def decay_gamma(chunk: int, ch_total: int) -> torch.Tensor:
+    """(Ch,Ch) retention matrix of form_decay (models/function.py:651-652, 684-732) in closed form:
+    Gamma[r, c] = mean_i d_i^(|r//S - c//S| + 1), d_i = exp(log(1 - 2^-(5 + chunk-1-i))), S = Ch / chunk,
+    powers by repeated multiplication (the reference's cumulative product)."""
+    S = ch_total // chunk
+    d = torch.log(1 - 2 ** (-5 - torch.arange(chunk - 1, -1, -1, dtype=torch.float))).exp()
+    powers = [d.clone()]
+    for _ in range(1, chunk):
+        powers.append(powers[-1] * d)
+    powers = torch.stack(powers, 1)
+    idx = torch.arange(chunk)
+    blk = powers[:, (idx[:, None] - idx[None, :]).abs()]
+    full = blk[:, :, None, :, None].expand(chunk, chunk, S, chunk, S).reshape(chunk, chunk * S, chunk * S)
+    return torch.mean(full, 0)
+
+
+class TAB(nn.Module):
+    """x += DP(spatial(LN2(x))) * s; x += DP(ffn(LN3(x))) * s (models/function.py:1139-1217)."""
+
+    def __init__(self, embed_dim, chunk_h, chunk_w, mlp_ratio, n_groups, qkv_bias, drop_path, ffn, mixer_scaling, channel_mixer):
+        super().__init__()
+        self.spatial_scale = mixer_scaling
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.spatial_mixing = Enhanced_MorphFCs_decay(embed_dim, chunk_h, chunk_w, qkv_bias, channel_mixer)
+        self.norm3 = nn.LayerNorm(embed_dim)
+        if ffn == "vanilla":
+            self.channel_mixing = Mlp(embed_dim, int(embed_dim * mlp_ratio))
+        elif ffn == "ffn_cnn":
+            self.channel_mixing = Mlp_cnn(embed_dim, exp_r=mlp_ratio, n_groups=n_groups)
+        else:
+            raise NotImplementedError(f"ffn_type {ffn!r} is not used by any shipped config")
+        self.drop_prob = float(drop_path)
+
+    def forward(self, x):
+        s = self.spatial_scale
+        dp = self.drop_prob > 0.0 and self.training
+        y = self.spatial_mixing(lnorm(self.norm2, x))
+        x = x + (_drop_path(y, self.drop_prob, self.training) * s if (dp or s != 1.0) else y)
+        n3 = lnorm(self.norm3, x)
+        if isinstance(self.channel_mixing, Mlp_cnn) and not dp and s == 1.0:
+            return self.channel_mixing(n3, res=x)  # residual fused in the Linear epilogue
+        return x + _drop_path(self.channel_mixing(n3), self.drop_prob, self.training) * s
+
+
+# ---------------------------------------------------------------------------------------------------------
+# trajectory attention + recurrent residual chains (models/trajectory.py)
+# ---------------------------------------------------------------------------------------------------------
+class ResidualBlockNoBN0(nn.Module):
+    def __init__(self, mid_channels, res_scale):
+        super().__init__()
+        self.res_scale = res_scale
+        self.conv1 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1)
+        self.conv2 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1)
+
+
+class ResidualBlocksWithInputConv(nn.Module):
+    """conv3x3(2C->C)+LeakyReLU(0.1), then num_blocks x [conv+ReLU, conv, x + r*out] (trajectory.py:16-52,165-221)."""
+
+    def __init__(self, in_channels, out_channels, num_blocks, r_scaling):
+        super().__init__()
+        self.main = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1), nn.LeakyReLU(0.1),
+                                  nn.Sequential(*[ResidualBlockNoBN0(out_channels, r_scaling) for _ in range(num_blocks)]))
+
+    def forward(self, srcs: Sequence[torch.Tensor]):
+        N, H, W, _ = srcs[0].shape
+        x = conv(self.main[0], srcs, N, H, W, act=ACT_LRELU, slope=0.1)
+        for blk in self.main[2]:
+            y = conv(blk.conv1, [x], N, H, W, act=ACT_RELU)
+            x = conv(blk.conv2, [y], N, H, W, alpha=blk.res_scale, res=x)
+        return x
+
+
+class LTAM_multi_head(nn.Module):
+    """Window trajectory attention (trajectory.py:493-547, 672-795), mode 'wins'."""
+
+    def __init__(self, embed_dim, head, if_scale, twins):
+        super().__init__()
+        self.head = head
+        self.scale = (embed_dim // head) ** -0.5 if if_scale else 1.0
+        self.proj = nn.Linear(embed_dim, embed_dim)
+        self.win_h, self.win_w = twins
+        self.relative_pos_encoding = nn.Parameter(torch.zeros(head, self.win_h * self.win_w, self.win_h * self.win_w))
+        nn.init.trunc_normal_(self.relative_pos_encoding, std=.02)
+        self.register_buffer("decay_v", 1 - 2 ** (-5 - torch.arange(head - 1, -1, -1, dtype=torch.float32)))
+
+    def forward(self, q, keys, anchor, vals, loc):
+        """q, anchor (n,h,w,c); keys, vals: lists of t tensors (n,h,w,c); loc (n,2t,h,w) -> (n,h,w,c)."""
+        att = FH.ltam_attention(q, keys, vals, loc, self.relative_pos_encoding, self.decay_v, self.head, self.win_h, self.win_w,
+                                self.scale)
+        return lin(self.proj, att, res=anchor)
+
+
+class Trajectory_multi_head(nn.Module):
+    """Bidirectional recurrence (trajectory.py:226-490): warp state by flow, attend to key-frame memory at tracked
+    locations, then the residual conv chain; finally fuse [backward, input, forward] with a 1x1 conv."""
+
+    def __init__(self, embed_dim, num_blocks, frame_stride, head, head_scale, r_scaling, twins):
+        super().__init__()
+        self.embed_dims = embed_dim
+        self.keyframe_stride = frame_stride
+        self.LTAM = LTAM_multi_head(embed_dim, head, head_scale, twins)
+        self.resblocks = ResidualBlocksWithInputConv(2 * embed_dim, embed_dim, num_blocks, r_scaling)
+        self.fusion = nn.Conv2d(3 * embed_dim, embed_dim, 1, 1, 0)
+
+    def _sweep(self, x, order, flow_of, key_idx):
+        n, t, h, w, c = x.shape
+        ident = FH.identity_grid(n, h, w, x.device)
+        feat = None
+        loc = ident
+        k_in: List[torch.Tensor] = []
+        k_state: List[torch.Tensor] = []
+        outs = {}
+        for step, i in enumerate(order):
+            cur = x[:, i]
+            if step == 0:
+                feat = torch.zeros_like(cur)
+            else:
+                fl = flow_of(i)  # (n,h,w,2) fp32
+                feat = flow_warp_nhwc(feat, fl, "bilinear", "border")
+                loc = FH.warp_locations(loc, fl)
+                feat = self.LTAM(cur, k_in, feat, k_state, loc)
+                if i in key_idx:
+                    loc = torch.cat([loc, ident], 1)
+            feat = self.resblocks([cur, feat])
+            if i in key_idx:
+                k_state.append(feat)
+                k_in.append(cur)
+            outs[i] = feat
+        return [outs[i] for i in range(t)]
+
+    def forward(self, x, flows_forward, flows_backward):
+        n, t, h, w, c = x.shape
+        fb = flows_backward.permute(0, 1, 3, 4, 2).float()
+        ff = flows_forward.permute(0, 1, 3, 4, 2).float()
+        s = self.keyframe_stride
+        back = self._sweep(x, list(range(t - 1, -1, -1)), lambda i: fb[:, i], list(range(t - 1, -1, -s)))
+        fwd = self._sweep(x, list(range(t)), lambda i: ff[:, i - 1], list(range(0, t, s)))
+        back, fwd = torch.stack(back, 1), torch.stack(fwd, 1)
+        out = conv(self.fusion, [back, x, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
+        return out.reshape(n, t, h, w, c)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3-D shifted-window attention (models/swin_3d.py), only with temporal_empty=False
+# ---------------------------------------------------------------------------------------------------------
+def _get_window_size(x_size, window_size, shift_size):
+    ws, ss = list(window_size), list(shift_size)
+    for i in range(3):
+        if x_size[i] <= window_size[i]:
+            ws[i] = x_size[i]
+            ss[i] = 0
+    return tuple(ws), tuple(ss)
+
+
+def _relative_position_index(ws) -> torch.Tensor:
+    coords = torch.stack(torch.meshgrid(torch.arange(ws[0]), torch.arange(ws[1]), torch.arange(ws[2]), indexing="ij"))
+    cf = coords.flatten(1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws[0] - 1
+    rel[:, :, 1] += ws[1] - 1
+    rel[:, :, 2] += ws[2] - 1
+    rel[:, :, 0] *= (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    rel[:, :, 1] *= 2 * ws[2] - 1
+    return rel.sum(-1)
+
+
+class rWindowAttention(nn.Module):
+    """Each time slice's queries attend to the tokens of the other slices of the window (swin_3d.py:120-252)."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        n_rel = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) * (2 * window_size[2] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(n_rel, num_heads))
+        self.register_buffer("relative_position_index", _relative_position_index(window_size))
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, 2 * dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, xw, mask):
+        q = lin(self.q, xw)
+        kv = lin(self.kv, xw)
+        o = FH.window_cross_slice_attention(q, kv, self.relative_position_bias_table, self.relative_position_index, mask,
+                                            self.num_heads, self.window_size)
+        return lin(self.proj, o)
+
+
+class EncoderBlockOnOnetoken(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, qkv_bias):
+        super().__init__()
+        self.window_size, self.shift_size, self.num_heads = tuple(window_size), tuple(shift_size), num_heads
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = rWindowAttention(dim, window_size, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, mask_full):
+        B, D, H, W, C = x.shape
+        ws, ss = _get_window_size((D, H, W), self.window_size, self.shift_size)
+        y = lnorm(self.norm1, x)
+        pd = (ws[0] - D % ws[0]) % ws[0]
+        pb = (ws[1] - H % ws[1]) % ws[1]
+        pr = (ws[2] - W % ws[2]) % ws[2]
+        shifted = any(s > 0 for s in ss)
+        yw, meta = FH.window_partition(y, ws, ss if shifted else (0, 0, 0), (pd, pb, pr))
+        aw = self.attn(yw, mask_full if shifted else None)
+        y = FH.window_reverse(aw, meta)
+        x = x + y
+        z = lnorm(self.norm2, x)
+        return lin(self.mlp.fc2, lin(self.mlp.fc1, z, act=ACT_GELU), res=x)
+
+
+class DecoderLayer(nn.Module):
+    """swin_3d.DecoderLayer (swin_3d.py:1108-1202): depth blocks, odd ones shifted by window/2."""
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, qkv_bias):
+        super().__init__()
+        self.window_size = list(window_size)
+        self.shift_size = [i // 2 for i in window_size]
+        self.blocks = nn.ModuleList([EncoderBlockOnOnetoken(dim, num_heads, window_size, [0, 0, 0] if i % 2 == 0 else self.shift_size,
+                                                            mlp_ratio, qkv_bias) for i in range(depth)])
+
+    def forward(self, x):
+        B, D, H, W, C = x.shape
+        wt = self.window_size[0]
+        seq_back = None
+        if D % wt != 0:  # rearrange_shape: repeat the last full-window frames in reverse (swin_3d.py:1141-1157)
+            delta_t = int(np.ceil(D / wt)) * wt - D
+            delta = list(range(-1, -(delta_t + 1), -1))
+            start = list(range(0, (D // wt) * wt))
+            end = list(range((D // wt) * wt, D))
+            new_seq = start + delta + end
+            seq_back = start + list(range(-1, -(len(end) + 1), -1))[::-1]
+            rep = [start[i] for i in delta]
+            x = torch.cat([x, x[:, rep]], 1)[:, new_seq].contiguous()
+            D = x.shape[1]
+        ws, ss = _get_window_size((D, H, W), self.window_size, self.shift_size)
+        Dp, Hp, Wp = (int(np.ceil(v / w)) * w for v, w in zip((D, H, W), ws))
+        mask = FH.shift_mask(Dp, Hp, Wp, ws, ss, x.device)
+        for blk in self.blocks:
+            x = blk(x, mask)
+        if seq_back is not None:
+            x = x[:, seq_back].contiguous()
+        return x
+
+
+# ---------------------------------------------------------------------------------------------------------
+# stage container, sampling, whole network
+# ---------------------------------------------------------------------------------------------------------
+class Mlp_encoder(nn.Module):
+    """TAB stack + local conv residual + temporal module (models/function.py:1267-1543); channels-last in/out."""
+
+    def __init__(self, embed_dim, depth, segm, chunk_dim_h, chunk_dim_w, mlp_ratio, n_groups, qkv_bias, drop_path, window_size,
+                 n_nonkeyframes, aligned, empty_aligned, traj_r_n, traj_heads, if_smooth, region_range, ffn_type, r_scaling, twins,
+                 traj_scale, m_scaling, if_local_fuse, channel_mixer):
+        super().__init__()
+        self.aligned, self.empty = aligned, empty_aligned
+        self.if_smooth, self.region_range = if_smooth, region_range
+        self.local_fuse = if_local_fuse
+        if if_local_fuse:
+            self.local_cnn = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
+        self.mlp_blocks = nn.ModuleList([TAB(embed_dim, chunk_dim_h, chunk_dim_w, mlp_ratio, n_groups, qkv_bias,
+                                             drop_path[i] if isinstance(drop_path, list) else drop_path, ffn_type, m_scaling,
+                                             channel_mixer) for i in range(depth)])
+        if aligned:
+            raise NotImplementedError("temporal_type=True (DCN alignment) is not configured by any shipped config")
+        if aligned is None:
+            self.traj_mixing = nn.Identity() if empty_aligned else DecoderLayer(embed_dim, 2, segm, window_size, mlp_ratio, qkv_bias)
+        else:
+            self.traj_mixing = Trajectory_multi_head(embed_dim, traj_r_n, n_nonkeyframes, traj_heads, traj_scale, r_scaling, twins)
+
+    @staticmethod
+    def flow_smoothing(flow, r):
+        """reflect-pad to a multiple of r, r x r mean, nearest x r, crop (function.py:1466-1478)."""
+        B, T, C, H, W = flow.shape
+        f = flow.reshape(-1, C, H, W)
+        hf, wf = int(np.ceil(H / r)) * r, int(np.ceil(W / r)) * r
+        f = F.pad(f, (0, wf - W, 0, hf - H), mode="reflect")
+        f = F.adaptive_avg_pool2d(f, (hf // r, wf // r))
+        f = F.interpolate(f, scale_factor=r, mode="nearest")[..., :H, :W].contiguous()
+        return f.view(B, T, C, H, W)
+
+    def forward(self, x, flow_forward=None, flow_backward=None):
+        B, T, H, W, C = x.shape
+        shortcut = x
+        if flow_forward is not None and self.if_smooth:
+            flow_backward = self.flow_smoothing(flow_backward, self.region_range)
+            flow_forward = self.flow_smoothing(flow_forward, self.region_range)
+        for blk in self.mlp_blocks:
+            x = blk(x)
+        if self.local_fuse:
+            x = conv(self.local_cnn, [x], B * T, H, W, res=shortcut.reshape(B * T, H, W, C)).reshape(B, T, H, W, C)
+        if self.aligned is None:
+            if not self.empty:
+                x = self.traj_mixing(x)
+        else:
+            x = self.traj_mixing(x, flow_forward, flow_backward)
+        return x
+
+
+class UpdownkeepSampling(nn.Module):
+    """space<->depth with channel order (neiw neih c), LayerNorm, Linear (models/layers.py:761-798)."""
+
+    def __init__(self, dim_in, dim_out, mode):
+        super().__init__()
+        self.mode = mode
+        cn = dim_in * 4 if mode == "down" else dim_in // 4
+        self.norm = nn.LayerNorm(cn)
+        self.linear = nn.Linear(cn, dim_out)
+
+    def forward(self, x):
+        y = FH.space_to_depth(x) if self.mode == "down" else FH.depth_to_space(x)
+        return lin(self.linear, lnorm(self.norm, y))
+
+
+class InputProj(nn.Module):
+    def __init__(self, in_channels, embed_dim):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_channels, embed_dim, 3, 1, 1), nn.LeakyReLU(inplace=True))
+
+
+class VMG(nn.Module):
+    def __init__(self, in_chans=3, embed_dim=[112, 224, 224, 448, 448, 224, 224, 112], depths=[8, 8, 8, 8, 8, 8, 8, 8],
+                 num_heads=[2, 4, 8, 16, 16, 8, 4, 2], num_frames=7,
+                 window_sizes=[(4, 4), (4, 4), (4, 4), (4, 4), (4, 4), (4, 4), (4, 4), (4, 4)], mdsc=True, if_concat=False,
+                 mlp_ratio=4., n_groups=1, qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1,
+                 norm_layer=nn.LayerNorm, patch_norm=True, back_RBs=0, spynet_pretrained=None, image_size=[64, 112], is_train=True,
+                 if_print=False, ltam=True, traj_win=[16, None, None, None], traj_keyframes_n=[3, None, None, None],
+                 traj_heads=[4, None, None, None], temporal_type=[False, None, None, None], temporal_empty=True,
+                 traj_res_n=[1, 0, 0, 0, 0, 0, 1], deform_groups=[8, 16, 16, 32], max_residual_scale=[1, 2, 2, 4],
+                 spatial_type=[False, False, False, False], flow_smooth=True, smooth_region_range=4, retention_decay=True,
+                 non_linear=True, gating=True, symm=True, symm_act=nn.Tanh, relu_scale=True, relu_scale_norm=False,
+                 ffn_type='vanilla', mixer_type=['mbconv', 'mbconv', 'mlps', 'mlps'], mixer_n=[2, 3, None, None], r_scaling=1.,
+                 chunk_ratios=[1 / 4, 1 / 4, 3 / 16, 1 / 8], traj_mode='wins', twins=[2, 2], traj_scale=True, traj_refine=None,
+                 m_scaling=1., if_local_fuse=False, channel_mixer='vanilla', compute_dtype=torch.float32):
+        super().__init__()
+        # --- options the hand-written path implements (every self-consistent shipped config)
+        if not (ltam and retention_decay and non_linear and gating and symm and relu_scale) or relu_scale_norm or if_concat:
+            raise NotImplementedError("VMG HIP path: ltam/retention_decay/non_linear/gating/symm/relu_scale must be true, "
+                                      "relu_scale_norm/if_concat false (as in all shipped configs)")
+        if symm_act not in ("tanh", nn.Tanh) or traj_mode != "wins" or any(m != "mlps" for m in mixer_type[:len(depths) // 2 + 1]):
+            raise NotImplementedError("VMG HIP path: symm_act='tanh', traj_mode='wins', mixer_type='mlps' only")
+        if back_RBs != 0 or traj_refine is not None:
+            raise NotImplementedError("back_RBs > 0 / traj_refine are not used by any shipped config")
+        self.num_layers = len(depths)
+        self.num_enc_layers = self.num_layers // 2 + 1
+        self.num_dec_layers = self.num_layers // 2
+        self.scale = 2 ** (self.num_enc_layers - 1)
+        dec_depths = depths[self.num_enc_layers:]
+        self.embed_dim = embed_dim
+        self.num_in_frames = num_frames
+        self.num_out_frames = num_frames
+        self.is_train = is_train
+        self.if_print = if_print
+        self.init_H, self.init_W = image_size
+        self.compute_dtype = compute_dtype
+        self.spynet = SPyNet(spynet_pretrained) if spynet_pretrained is not None else None
+
+        enc_dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths[:self.num_enc_layers]))]
+        dec_dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths[self.num_enc_layers:]))][::-1]
+        if not is_train:
+            enc_dpr, dec_dpr = [0.] * len(enc_dpr), [0.] * len(dec_dpr)
+        self.chunk_ratio = [float(Fraction(r)) for r in chunk_ratios]
+        self.chunk_h = [int(self.init_H * x) for x in self.chunk_ratio]
+        self.chunk_w = [int(self.init_W * x) for x in self.chunk_ratio]
+        self.local_fuse = if_local_fuse
+        if if_local_fuse:
+            self.local_cnn = nn.Conv2d(embed_dim[0], embed_dim[0], 3, 1, 1)
+        self.input_proj = InputProj(in_chans, embed_dim[0])
+
+        def stage(dim, depth, heads, ch, cw, dpr, ws, nk, al, rn, th):
+            return Mlp_encoder(dim, depth, heads, ch, cw, mlp_ratio, n_groups, qkv_bias, dpr, ws, nk, al, temporal_empty, rn, th,
+                               flow_smooth, smooth_region_range, ffn_type, r_scaling, twins, traj_scale, m_scaling, if_local_fuse,
+                               channel_mixer)
+
+        self.encoder_layers, self.upsample, self.downsample = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for i in range(self.num_enc_layers):
+            self.encoder_layers.append(stage(embed_dim[i], depths[i], num_heads[i], self.chunk_h[i], self.chunk_w[i],
+                                             enc_dpr[sum(depths[:i]):sum(depths[:i + 1])], window_sizes[i], traj_keyframes_n[i],
+                                             temporal_type[i], traj_res_n[i], traj_heads[i]))
+            if i != self.num_enc_layers - 1:
+                self.downsample.append(UpdownkeepSampling(embed_dim[i], embed_dim[i + 1], "down"))
+            else:
+                self.upsample.append(UpdownkeepSampling(embed_dim[i], embed_dim[i + 1], "up"))
+        self.decoder_layers = nn.ModuleList()
+        ne = self.num_enc_layers
+        for i in range(self.num_dec_layers):
+            self.decoder_layers.append(stage(embed_dim[i + ne], depths[i + ne], num_heads[i + ne], self.chunk_h[-i - 2],
+                                             self.chunk_w[-i - 2], dec_dpr[sum(dec_depths[:i]):sum(dec_depths[:i + 1])],
+                                             window_sizes[i + ne], traj_keyframes_n[-i - 2], temporal_type[-i - 2], traj_res_n[i + ne],
+                                             traj_heads[-i - 2]))
+            if i != self.num_dec_layers - 1:
+                self.upsample.append(UpdownkeepSampling(embed_dim[i + ne], embed_dim[i + ne + 1], "up"))
+
+        self.upconv1 = nn.Conv2d(embed_dim[-1], embed_dim[-1] * 4, 3, 1, 1)
+        self.upconv2 = nn.Conv2d(embed_dim[-1], 64 * 4, 3, 1, 1)
+        self.HRconv = nn.Conv2d(64, 64, 3, 1, 1)
+        self.conv_last = nn.Conv2d(64, 3, 3, 1, 1)
+        self.mdsc = mdsc
+        if mdsc:
+            self.sc_64_16 = nn.Sequential(nn.Conv2d(embed_dim[0], embed_dim[2], 1, 1, 0), nn.GroupNorm(1, embed_dim[2]), nn.ReLU())
+            self.sc_32_8 = nn.Sequential(nn.Conv2d(embed_dim[1], embed_dim[3], 1, 1, 0), nn.GroupNorm(1, embed_dim[3]), nn.ReLU())
+        self.mlp_wd_param = [p for name, p in self.named_parameters() if ".mlp_blocks." in name]
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---------------------------------------------------------------------------------------------- flows
+    def check_frames_mirror(self, lrs):
+        self.frames_mirror = False
+        if lrs.size(1) % 2 == 0:
+            a, b = torch.chunk(lrs, 2, dim=1)
+            if torch.linalg.norm(a - b.flip(1)) == 0:
+                self.frames_mirror = True
+
+    def compute_flow(self, lrs):
+        """Per encoder scale: SPyNet forward/backward flows (models/vmg.py:435-464)."""
+        B, T, C, H, W = lrs.shape
+        fwd, bwd = [], []
+        for i in range(self.num_enc_layers):
+            h, w = H // (2 ** i), W // (2 ** i)
+            xi = F.adaptive_avg_pool2d(lrs.reshape(B * T, C, H, W), (h, w)).reshape(B, T, C, h, w)
+            a = xi[:, :-1].reshape(-1, C, h, w)
+            b = xi[:, 1:].reshape(-1, C, h, w)
+            ff = self.spynet(b, a).view(B, T - 1, 2, h, w)
+            fb = ff.flip(1) if self.frames_mirror else self.spynet(a, b).view(B, T - 1, 2, h, w)
+            fwd.append(ff)
+            bwd.append(fb)
+        return fwd, bwd
+
+    # ---------------------------------------------------------------------------------------------- trunk
+    def _mdsc(self, seq, x):
+        B, T, H, W, C = x.shape
+        f = F.adaptive_max_pool2d(x.reshape(B * T, H, W, C).permute(0, 3, 1, 2).float(), (H // 4, W // 4))
+        f = F.relu(F.group_norm(F.conv2d(f, seq[0].weight, seq[0].bias), 1, seq[1].weight, seq[1].bias, seq[1].eps))
+        return f.permute(0, 2, 3, 1).reshape(B, T, H // 4, W // 4, -1).to(x.dtype)
+
+    def forward_features_multi_stages(self, x, ff, fb):
+        enc, dec, down, up = self.encoder_layers, self.decoder_layers, self.downsample, self.upsample
+        x1 = enc[0](x, ff[0], fb[0])
+        x1_3 = self._mdsc(self.sc_64_16, x1) if self.mdsc else 0
+        x2 = enc[1](down[0](x1), ff[1], fb[1])
+        x2_4 = self._mdsc(self.sc_32_8, x2) if self.mdsc else 0
+        x3 = enc[2](down[1](x2), ff[2], fb[2])
+        x4 = enc[3](down[2](x3 + x1_3), ff[3], fb[3])
+        x5 = dec[0](up[0](x4 + x2_4), ff[2], fb[2])
+        x6 = dec[1](up[1](x5 + x3), ff[1], fb[1])
+        x7 = dec[2](up[2](x6 + x2), ff[0], fb[0])
+        return x7 + x1
+
+    def forward_features_few_stages(self, x, ff, fb):
+        x1 = self.encoder_layers[0](x, ff[0], fb[0])
+        x2 = self.encoder_layers[1](self.downsample[0](x1), ff[1], fb[1])
+        x3 = self.decoder_layers[0](self.upsample[0](x2), ff[0], fb[0])
+        return x3 + x1
+
+    def forward(self, x, flow_pretrained=None, config_amp=None):
+        B, D, C, H, W = x.size()
+        assert H >= 64 and W >= 64, "The height and width must larger than 64."
+        hip.require_cuda(x)
+        if self.spynet is None:
+            raise HipError("VMG.spynet is None: the trajectory modules need optical flow (the reference crashes here too, "
+                           "models/trajectory.py:329); construct with spynet_pretrained or attach SPyNet(None)")
+        in_dtype = x.dtype
+        x = x.float()
+        self.check_frames_mirror(lrs=x)
+        up = F.interpolate(x.reshape(B * D, C, H, W), scale_factor=4, mode="bilinear", align_corners=False)  # == trilinear with D kept
+        Hp = int(np.ceil(H / self.scale)) * self.scale
+        Wp = int(np.ceil(W / self.scale)) * self.scale
+        x = F.pad(x, (0, Wp - W, 0, Hp - H, 0, 0), mode="replicate")
+        ff, fb = self.compute_flow(x)
+        cd = self.compute_dtype
+        xin = x.reshape(B * D, C, Hp, Wp).permute(0, 2, 3, 1).contiguous().to(cd)  # channels-last frames
+        feat = conv(self.input_proj.proj[0], [xin], B * D, Hp, Wp, act=ACT_LRELU, slope=0.01).reshape(B, D, Hp, Wp, -1)
+        if self.num_layers > 3:
+            y = self.forward_features_multi_stages(feat, ff, fb)
+        else:
+            y = self.forward_features_few_stages(feat, ff, fb)
+        N = B * D
+        if self.local_fuse:
+            y = conv(self.local_cnn, [y], N, Hp, Wp, res=feat.reshape(N, Hp, Wp, -1))
+        y = y.reshape(N, Hp, Wp, -1)[:, :H, :W].contiguous()
+        o = conv(self.upconv1, [y], N, H, W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
+        o = conv(self.upconv2, [o], N, 2 * H, 2 * W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
+        o = conv(self.HRconv, [o], N, 4 * H, 4 * W, act=ACT_LRELU, slope=0.1)
+        o = conv(self.conv_last, [o], N, 4 * H, 4 * W)
+        out = o.float().permute(0, 3, 1, 2) + up
+        return out.reshape(B, self.num_out_frames, -1, 4 * H, 4 * W).to(in_dtype)
