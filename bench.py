@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- VMG-REDS-few_levels training step (forward + loss + backward + AdamW) on synthetic REDS-shaped clips.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload = BASELINE.json configs[1]: per-GPU batch 4 x 7 x 3 x 64 x 64, 4x SR, bf16 activations (fp32 accumulate,
+fp32 master weights), random-init weights, synthetic data resident in HBM before the timed region.  One "step" is one
+pass of the hot path over one batch.  Prints ONE JSON line on rank 0 with the whole-job LR-frames/s, the roofline
+object of the dominant kernel (live HIP-event timing of the bf16 conv3x3 144->144 implicit-GEMM kernel) and the CPU
+baseline (the oracle, i.e. this repo's CPU restatement, on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, T, H, W = 4, 7, 64, 64
+FWD_GFLOP_PER_FRAME = 292.8  # Conv+Linear, measured on the reference (SURVEY section 6 / BASELINE.md section 2)
+K1_FLOPS_PER_PIXEL = 2.0 * 144 * 144 * 9  # the dominant kernel: conv3x3 144->144
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(device):
+    import vmg_amd
+    from vmg_amd.data import REDS_FEW_LEVELS
+    torch.manual_seed(0)
+    m = vmg_amd.VMG(num_frames=T, image_size=[64, 64], is_train=True, spynet_pretrained=None, compute_dtype=torch.bfloat16,
+                    **REDS_FEW_LEVELS)
+    m.spynet = vmg_amd.SPyNet(None)  # the configs' SPyNet checkpoint is a download URL: random init, as stated in "data"
+    return m.to(device).train()
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (CPU restatement, fp32, all host cores) forward + loss + backward on a bounded sample of the workload."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from oracle import vmg_oracle as O
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncores)))  # the GPU box gives one GPU a 16-core share; never oversubscribe
+    cfg = C.cfg_reds_few(T=5)
+    shapes, _ = C.load_fixture(os.path.join(ROOT, "tests", "golden", "vmg_reds_few_cfg1.npz"))
+    chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+    sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not R.is_buffer(k):
+            v.requires_grad_(True)
+    x = R.synthetic_clip(1, 5, 64, 64, 7)
+    y = R.synthetic_target(x)
+    t0 = time.time()
+    out = O.vmg_forward(sd, cfg, x, mutate=False, call_index=1)
+    print("[bench] cpu_baseline forward %.1f s" % (time.time() - t0), file=sys.stderr, flush=True)
+    loss = O.charbonnier_edge_loss(out, y)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(5.0 / dt, 4), "unit": "LR-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 clip x 5 frames x 64x64, fp32, forward+loss+backward once (%.1f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the VMG hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from vmg_amd import hip
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    from vmg_amd.train import TrainStep
+
+    model = build_model(device)
+    step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
+    lrs = synthetic_clip(B_PER_GPU, T, H, W, seed=1234 + rank, device=device)
+    hrs = synthetic_target(lrs, seed=4321 + rank)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(lrs, hrs)
+    barrier()
+    if rank == 0:
+        print("[bench] warmup done", file=sys.stderr, flush=True)
+    lib = hip.lib()
+    if not args.no_prof:
+        hip.check(lib.vmg_prof_begin(1, 16, 4096), "vmg_prof_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(lrs, hrs)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    roofline = None
+    if not args.no_prof:
+        seen, n, ms = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0.0)
+        hip.check(lib.vmg_prof_end(ctypes.byref(seen), ctypes.byref(n), ctypes.byref(ms)), "vmg_prof_end")
+        if n.value > 0:
+            avg_s = ms.value / n.value * 1e-3
+            flops = K1_FLOPS_PER_PIXEL * B_PER_GPU * H * W  # algorithmic FLOPs of one launch (M = 16384 pixels)
+            ach = flops / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,3,1,9> (conv3x3 144->144, fwd+dgrad)",
+                        "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": seen.value // max(1, args.steps),
+                        "samples": n.value}
+
+    if rank == 0:
+        print("[bench] timed region done: %.3f s for %d steps" % (dt, args.steps), file=sys.stderr, flush=True)
+    frames = world * B_PER_GPU * T * args.steps
+    value = frames / dt
+    line = {
+        "metric": "LR-frames/s (train: forward+loss+backward+AdamW), VMG-REDS-few_levels 4x SR",
+        "value": round(value, 3), "unit": "LR-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
+        "config": {"workload": "VMG-REDS-few_levels train step, per-GPU batch 4x7x3x64x64 -> 4x SR (BASELINE configs[1])",
+                   "global_batch": world * B_PER_GPU, "frames_per_clip": T, "lr_size": [H, W], "parallelism": f"dp{world}",
+                   "per_gpu_value": round(value / world, 3),
+                   "model_tflops": round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2), "loss": float(loss)},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,6 +131,15 @@ int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, 
 int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,
                       float* dw, float* db, int64_t M, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Live kernel timing (bench.py roofline object): HIP events are recorded on the launch stream around every
+ * `stride`-th launch of kernel class `klass` (1 = bf16 conv3x3 144->144, the trajectory-chain kernel, forward
+ * and data-gradient alike) until `max_samples` pairs are used.  vmg_prof_end synchronises those events and
+ * returns the number of launches seen, the samples taken and their summed duration in milliseconds.
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_prof_begin(int klass, int stride, int max_samples);
+int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

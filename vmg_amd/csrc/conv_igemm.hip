@@ -379,7 +379,10 @@ int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   }
   long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
+  // the dominant kernel class of the path: bf16 3x3, one source of 144 channels, 144 outputs (trajectory chains)
+  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, k);
+  if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -15,3 +15,53 @@ void vmg_set_error(const char* fmt, ...) {
 extern "C" const char* vmg_last_error(void) { return g_err; }
 extern "C" int vmg_version(void) { return 100; }
 extern "C" int vmg_max_lds_bytes(void) { return 160 * 1024; }
+
+// ------------------------------------------------------------------------------------------------------
+// Live kernel timing for bench.py's roofline object: HIP events recorded on the launch stream around every
+// `stride`-th launch of the kernel class selected with vmg_prof_begin.  Reading the result synchronises.
+// ------------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct Prof {
+  int klass = 0, stride = 1;
+  long long seen = 0;
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t used = 0;
+} g_prof;
+}  // namespace
+
+bool vmg_prof_before(int klass, hipStream_t st) {
+  if (g_prof.klass == 0 || klass != g_prof.klass) return false;
+  if ((g_prof.seen++ % g_prof.stride) != 0 || g_prof.used + 2 > g_prof.ev.size()) return false;
+  (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  return true;
+}
+void vmg_prof_after(hipStream_t st) {
+  (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+  g_prof.used += 2;
+}
+
+extern "C" int vmg_prof_begin(int klass, int stride, int max_samples) {
+  VMG_CHECK(klass > 0 && stride > 0 && max_samples > 0, "prof_begin: bad arguments");
+  g_prof.klass = klass; g_prof.stride = stride; g_prof.seen = 0; g_prof.used = 0;
+  while (g_prof.ev.size() < (size_t)max_samples * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { vmg_set_error("prof_begin: hipEventCreate failed"); return -2; }
+    g_prof.ev.push_back(e);
+  }
+  return 0;
+}
+
+extern "C" int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms) {
+  VMG_CHECK(launches_seen && samples && total_ms, "prof_end: null pointer");
+  double tot = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) { tot += ms; ++n; }
+  }
+  *launches_seen = g_prof.seen; *samples = n; *total_ms = tot;
+  g_prof.klass = 0; g_prof.used = 0;
+  return 0;
+}

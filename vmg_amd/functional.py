@@ -98,6 +98,8 @@ class _Conv2d(torch.autograd.Function):
                                   pixel_shuffle=pixel_shuffle, want_pre=need_pre)
         ctx.cfg = cfg
         ctx.src_ch = src_ch
+        ctx.src_shapes = [tuple(t.shape) for t in srcs]
+        ctx.res_shape = tuple(res.shape) if res is not None else None
         ctx.has_res = res is not None
         ctx.has_bias = bias is not None
         # relu / lrelu derivatives come from the sign of the output (taken before the residual is added, so keep
@@ -113,7 +115,7 @@ class _Conv2d(torch.autograd.Function):
         weight, y, pre = ctx.saved_tensors[:3]
         srcs_p = ctx.saved_tensors[3:]
         dy = dy.contiguous()
-        d_res = dy if ctx.has_res else None
+        d_res = dy.reshape(ctx.res_shape) if ctx.has_res else None
         if pixel_shuffle:
             # undo the depth-to-space on the gradient (and on y for the activation derivative)
             dy = K.pixel_unshuffle(dy, N, H, W)
@@ -129,7 +131,7 @@ class _Conv2d(torch.autograd.Function):
             if ctx.needs_input_grad[4 + i]:
                 pw = packed(weight, dpre.dtype, "dgrad", None, off, c)
                 dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W)
-                d_srcs.append(dx)
+                d_srcs.append(dx.reshape(ctx.src_shapes[i]))
             else:
                 d_srcs.append(None)
             off += c

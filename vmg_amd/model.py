@@ -344,16 +344,16 @@ class Trajectory_multi_head(nn.Module):
         self.resblocks = ResidualBlocksWithInputConv(2 * embed_dim, embed_dim, num_blocks, r_scaling)
         self.fusion = nn.Conv2d(3 * embed_dim, embed_dim, 1, 1, 0)
 
-    def _sweep(self, x, order, flow_of, key_idx):
-        n, t, h, w, c = x.shape
-        ident = FH.identity_grid(n, h, w, x.device)
+    def _sweep(self, xt, order, flow_of, key_idx):
+        t, n, h, w, c = xt.shape
+        ident = FH.identity_grid(n, h, w, xt.device)
         feat = None
         loc = ident
         k_in: List[torch.Tensor] = []
         k_state: List[torch.Tensor] = []
         outs = {}
         for step, i in enumerate(order):
-            cur = x[:, i]
+            cur = xt[i]
             if step == 0:
                 feat = torch.zeros_like(cur)
             else:
@@ -372,14 +372,15 @@ class Trajectory_multi_head(nn.Module):
 
     def forward(self, x, flows_forward, flows_backward):
         n, t, h, w, c = x.shape
-        fb = flows_backward.permute(0, 1, 3, 4, 2).float()
-        ff = flows_forward.permute(0, 1, 3, 4, 2).float()
+        xt = x.transpose(0, 1).contiguous()  # time-major: every frame batch xt[i] is a dense (n,h,w,c) pixel array
+        fb = flows_backward.permute(1, 0, 3, 4, 2).float().contiguous()
+        ff = flows_forward.permute(1, 0, 3, 4, 2).float().contiguous()
         s = self.keyframe_stride
-        back = self._sweep(x, list(range(t - 1, -1, -1)), lambda i: fb[:, i], list(range(t - 1, -1, -s)))
-        fwd = self._sweep(x, list(range(t)), lambda i: ff[:, i - 1], list(range(0, t, s)))
-        back, fwd = torch.stack(back, 1), torch.stack(fwd, 1)
-        out = conv(self.fusion, [back, x, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
-        return out.reshape(n, t, h, w, c)
+        back = self._sweep(xt, list(range(t - 1, -1, -1)), lambda i: fb[i], list(range(t - 1, -1, -s)))
+        fwd = self._sweep(xt, list(range(t)), lambda i: ff[i - 1], list(range(0, t, s)))
+        back, fwd = torch.stack(back, 0), torch.stack(fwd, 0)
+        out = conv(self.fusion, [back, xt, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
+        return out.reshape(t, n, h, w, c).transpose(0, 1).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------------
