@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     net = _Net()
     net.gamma.fill_(float(rank + 5))
     broadcast_module_state(net)
-    red = GradBucketReducer(net.parameters(), bucket_bytes=2048)  # several small buckets
+    red = GradBucketReducer(net.parameters(), bucket_bytes=512)  # several small buckets
     outs = []
     for step in range(2):
         torch.manual_seed(7 + 10 * step + rank)
