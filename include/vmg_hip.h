@@ -110,6 +110,12 @@ int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
 int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_t x_ps, int Cin, const void* dy,
                    int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
                    void* stream);
+/* The same, summed over `npairs` (1..16) pairs (x[p], dy[p]) of identical shape and strides in ONE launch: the uses of a
+ * weight that the recurrence shares over frames and directions (models/trajectory.py:361,448 call one module 2T times).
+ * x and dy are HOST arrays of device pointers. */
+int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
+                           int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db,
+                           float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound, one pass, 16-byte vectors).

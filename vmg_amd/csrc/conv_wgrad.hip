@@ -19,11 +19,15 @@
 
 namespace {
 
+constexpr int WG_MAX_PAIRS = 16;  // (x, dy) pairs summed by one launch (uses of a shared weight)
+
 struct WgradK {
-  const char* x;
+  const char* x[WG_MAX_PAIRS];
+  const char* dy[WG_MAX_PAIRS];
+  int npairs;
+  long long Upair;  // K units per pair
   long long x_ps;
   int Cin;
-  const char* dy;
   long long dy_ps;
   int Cout;
   float* dW;
@@ -91,8 +95,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
 
   uint4 rdy[C::DY_NV], rx[C::X_NV];
 
-  auto load_unit = [&](long long u) {
-    // pixel coordinates of the unit
+  auto load_unit = [&](long long ug) {
+    // which (x, dy) pair, then pixel coordinates of the unit inside it
+    const int pair = (int)(ug / a.Upair);
+    const long long u = ug - (long long)pair * a.Upair;
+    const char* xbase = a.x[pair];
+    const char* dybase = a.dy[pair];
     int n = 0, y = 0, x0 = 0;
     long long m0 = 0;
     if (KS == 3) {
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       if (KS == 3) { ok = ok && (x0 + p < a.W); pix = ((long long)n * a.H + y) * a.W + x0 + p; }
       else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
       if (ok) {
-        const char* src = a.dy + (pix * a.dy_ps + c) * ES;
+        const char* src = dybase + (pix * a.dy_ps + c) * ES;
         if (a.vec_ok && c + C::VPL <= a.Cout) {
           val = *reinterpret_cast<const uint4*>(src);
         } else {
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
         pix = m0 + p;
       }
       if (ok) {
-        const char* src = a.x + (pix * a.x_ps + c) * ES;
+        const char* src = xbase + (pix * a.x_ps + c) * ES;
         if (a.vec_ok && c + C::VPL <= a.Cin) {
           val = *reinterpret_cast<const uint4*>(src);
         } else {
@@ -258,7 +266,7 @@ int launch_wgrad(WgradK k, hipStream_t st) {
   static_assert(C::LDS_BYTES <= 160 * 1024, "wgrad LDS");
   const int gx = cdiv(k.Cout, C::DYC), gy = cdiv(k.Cin, C::XC);
   long long s = 1024 / ((long long)gx * gy);  // ~4 workgroups per CU in flight
-  if (s > k.U / 4) s = k.U / 4;
+  if (s > k.U / 32) s = k.U / 32;           // >= 8 K units per wave, or the float-atomic epilogue dominates
   if (s < 1) s = 1;
   if (s > 65535) s = 65535;
   k.S = (int)s;
@@ -275,24 +283,43 @@ int launch_wgrad(WgradK k, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_t x_ps, int Cin, const void* dy,
-                              int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
-                              void* stream) {
+static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps,
+                      int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale, void* stream) {
   VMG_CHECK(ks == 1 || ks == 3, "conv_wgrad: ks must be 1 or 3");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_wgrad: bad dtype");
   VMG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
-  VMG_CHECK(x && dy && dW, "conv_wgrad: null pointer");
+  VMG_CHECK(npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW, "conv_wgrad: 1..%d (x, dy) pairs", WG_MAX_PAIRS);
   VMG_CHECK(x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad strides / slices");
   const int es = dtype == VMG_BF16 ? 2 : 4, vpl = 16 / es;
   WgradK k;
   memset(&k, 0, sizeof(k));
-  k.x = (const char*)x; k.x_ps = x_ps; k.Cin = Cin; k.dy = (const char*)dy; k.dy_ps = dy_ps; k.Cout = Cout;
+  k.vec_ok = (x_ps % vpl == 0) && (dy_ps % vpl == 0);
+  for (int p = 0; p < npairs; ++p) {
+    VMG_CHECK(x[p] && dy[p], "conv_wgrad: null pointer in pair %d", p);
+    k.x[p] = (const char*)x[p];
+    k.dy[p] = (const char*)dy[p];
+    k.vec_ok = k.vec_ok && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
+  }
+  k.npairs = npairs;
+  k.x_ps = x_ps; k.Cin = Cin; k.dy_ps = dy_ps; k.Cout = Cout;
   k.dW = dW; k.I_total = I_total; k.o0 = o0; k.i0 = i0; k.db = db; k.scale = scale;
   k.N = N; k.H = H; k.W = W; k.M = (long long)N * H * W;
   k.SEG = cdiv(W, 32);
-  k.U = ks == 3 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
-  k.vec_ok = ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (x_ps % vpl == 0) && (dy_ps % vpl == 0);
+  k.Upair = ks == 3 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
+  k.U = k.Upair * npairs;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
   return ks == 3 ? launch_wgrad<float, 3, 3, 1>(k, st) : launch_wgrad<float, 1, 3, 3>(k, st);
+}
+
+extern "C" int vmg_conv_wgrad(int dtype, int ks, int N, int H, int W, const void* x, int64_t x_ps, int Cin, const void* dy,
+                              int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale,
+                              void* stream) {
+  return wgrad_impl(dtype, ks, 1, &x, &dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
+}
+
+extern "C" int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
+                                      int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0,
+                                      float* db, float scale, void* stream) {
+  return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
 }

@@ -76,6 +76,73 @@ def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:
     return torch.nn.functional.pad(t, (0, _pad_to(c, mult) - c))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# deferred, batched weight gradients
+#
+# The recurrence applies one conv module to every frame in both directions (2T uses per step).  A weight gradient
+# per use has K = B*H*W pixels against a 144x144x9 fp32 output, so its float-atomic epilogue dominates.  Instead,
+# backward only RECORDS (input, output-gradient) pairs; when the last use of a parameter has been seen the pairs
+# are summed by ONE batched launch straight into param.grad (no zero-fill, no autograd accumulate kernels).
+# 288 GB of HBM make keeping the pairs alive until then a non-issue.
+# ---------------------------------------------------------------------------------------------------------
+class _DeferredWgrad:
+    def __init__(self):
+        self.uses = {}      # id(param) -> outstanding forward uses
+        self.pending = {}   # id(param) -> [weight, bias, entries]
+        self.callbacks = []  # called with each parameter whose .grad has just been completed
+
+    def note_use(self, weight):
+        self.uses[id(weight)] = self.uses.get(id(weight), 0) + 1
+
+    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W):
+        ent = self.pending.setdefault(id(weight), [weight, bias, []])
+        ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W))
+        left = self.uses.get(id(weight), 1) - 1
+        if left <= 0:
+            self.uses.pop(id(weight), None)
+            self.flush(weight)
+        else:
+            self.uses[id(weight)] = left
+
+    def flush(self, weight):
+        ent = self.pending.pop(id(weight), None)
+        if ent is None:
+            return
+        weight, bias, entries = ent
+        if weight.grad is None:
+            weight.grad = torch.zeros_like(weight, dtype=torch.float32)
+        if bias is not None and bias.requires_grad and bias.grad is None:
+            bias.grad = torch.zeros_like(bias, dtype=torch.float32)
+        db = bias.grad if (bias is not None and bias.requires_grad) else None
+        groups = {}
+        for e in entries:
+            sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]))
+            groups.setdefault(sig, []).append(e)
+        for (src_ch, ks, N, H, W, _, _), es in groups.items():
+            off = 0
+            for i, c in enumerate(src_ch):
+                xs = [e[0][i][..., :c] if e[0][i].shape[-1] != c else e[0][i] for e in es]
+                K.conv_wgrad_batched(xs, [e[2] for e in es], weight.grad, db if i == 0 else None, ks, N, H, W, i0=off)
+                off += c
+        for cb in self.callbacks:
+            cb(weight)
+            if db is not None:
+                cb(bias)
+
+    def flush_all(self):
+        for key in list(self.pending):
+            self.flush(self.pending[key][0])
+        self.uses.clear()
+
+
+DEFERRED = _DeferredWgrad()
+
+
+def flush_deferred_wgrads():
+    """Safety net after backward: completes gradients whose use count never reached zero (part of the graph unused)."""
+    DEFERRED.flush_all()
+
+
 def _act_grad(dy: torch.Tensor, y: Optional[torch.Tensor], pre: Optional[torch.Tensor], act: int, slope: float, alpha: float):
     """d(out)/d(pre) applied to dy for out = act(pre) * alpha."""
     if act == hip.ACT_NONE:
@@ -102,6 +169,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.res_shape = tuple(res.shape) if res is not None else None
         ctx.has_res = res is not None
         ctx.has_bias = bias is not None
+        ctx.defer = isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[0] and (bias is None or isinstance(bias, torch.nn.Parameter))
+        if ctx.defer:
+            DEFERRED.note_use(weight)
+            ctx.bias_ref = bias
         # relu / lrelu derivatives come from the sign of the output (taken before the residual is added, so keep
         # the sign information only when there is no residual; with a residual the activation is NONE on this path)
         if act in (hip.ACT_RELU, hip.ACT_LRELU) and res is not None:
@@ -135,7 +206,9 @@ class _Conv2d(torch.autograd.Function):
             else:
                 d_srcs.append(None)
             off += c
-        if ctx.needs_input_grad[0]:
+        if ctx.defer:
+            DEFERRED.add(weight, ctx.bias_ref, list(srcs_p), ctx.src_ch, dpre, ks, N, H, W)
+        elif ctx.needs_input_grad[0]:
             d_w = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
             d_b = torch.zeros(O, dtype=torch.float32, device=weight.device) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
             off = 0

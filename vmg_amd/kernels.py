@@ -241,3 +241,33 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
                                           w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
               "vmg_layernorm_bwd")
     return dx, dw, db
+
+
+def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], dW: torch.Tensor, db: Optional[torch.Tensor], ks: int,
+                       N: int, H: int, W: int, scale: float = 1.0, o0: int = 0, i0: int = 0):
+    """dW += scale * sum_p wgrad(xs[p], dys[p]) in as few launches as possible (16 pairs per launch)."""
+    if len(xs) != len(dys) or not xs:
+        raise HipError("conv_wgrad_batched: need equally many x and dy tensors")
+    x0, d0 = xs[0], dys[0]
+    hip.require_cuda(dW, db, *xs, *dys)
+    if dW.dtype != torch.float32 or not dW.is_contiguous() or (db is not None and (db.dtype != torch.float32 or not db.is_contiguous())):
+        raise HipError("parameter gradients must be contiguous fp32")
+    M = N * H * W
+    Cin, Cout = x0.shape[-1], d0.shape[-1]
+    xps, dps = _pix_stride(x0), _pix_stride(d0)
+    for x, d in zip(xs, dys):
+        if x.dtype != x0.dtype or d.dtype != x0.dtype or x.shape[-1] != Cin or d.shape[-1] != Cout or x.numel() // Cin != M or \
+                d.numel() // Cout != M or _pix_stride(x) != xps or _pix_stride(d) != dps:
+            raise HipError("conv_wgrad_batched: all pairs must share shape, dtype and strides")
+    O_total, I_total = dW.shape[0], dW.shape[1]
+    kk = 1 if dW.dim() == 2 else dW.shape[2]
+    if kk != ks or o0 + Cout > O_total or i0 + Cin > I_total or (db is not None and db.numel() != O_total):
+        raise HipError(f"gradient tensor {tuple(dW.shape)} does not match conv (ks={ks}, Cout={Cout}+{o0}, Cin={Cin}+{i0})")
+    code = hip.dtype_code(x0.dtype)
+    l = hip.lib()
+    for s in range(0, len(xs), 16):
+        n = min(16, len(xs) - s)
+        xa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xs[s:s + n]])
+        da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys[s:s + n]])
+        hip.check(l.vmg_conv_wgrad_batched(code, ks, n, xa, da, N, H, W, xps, Cin, dps, Cout, dW.data_ptr(), I_total, o0, i0,
+                                           db.data_ptr() if db is not None else None, scale, hip.stream_ptr()), "vmg_conv_wgrad_batched")

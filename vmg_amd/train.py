@@ -106,11 +106,18 @@ class GradBucketReducer:
         self.enabled = True
         self.side = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._seen = set()
+        try:  # conv / linear weights are completed by the deferred batched weight-gradient, not by autograd accumulation
+            from . import functional as FH
+            FH.DEFERRED.callbacks[:] = [self._on_grad]  # one reducer per process
+        except Exception:  # pragma: no cover
+            pass
         self.reset()
 
     def reset(self):
         self.pending = [len(b) for b in self.buckets]
         self.works = []
+        self._seen = set()
 
     def _launch(self, bi: int):
         b, flat = self.buckets[bi], self.flat[bi]
@@ -128,8 +135,9 @@ class GradBucketReducer:
         self.works.append((bi, work))
 
     def _on_grad(self, p: torch.nn.Parameter):
-        if not self.enabled:
+        if not self.enabled or p not in self.bucket_of or id(p) in self._seen:
             return
+        self._seen.add(id(p))
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
@@ -186,10 +194,16 @@ class TrainStep:
         if distributed:
             broadcast_module_state(model)
 
+    @staticmethod
+    def _flush():
+        from . import functional as FH
+        FH.flush_deferred_wgrads()
+
     def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
         out = self.model(lrs)
         loss = charbonnier_edge_loss(out.float(), hrs.float(), **self.loss_args)
         loss.backward()
+        self._flush()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
