@@ -138,6 +138,35 @@ int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mea
                       float* dw, float* db, int64_t M, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Flow-guided sampling of the trajectory recurrence (models/trajectory.py:71-116 flow_warp, :329-333, :414-417).
+ * flow: (N,H,W,2) fp32 pixel offsets (x then y); coordinates follow flow_warp + F.grid_sample(align_corners=True).
+ *   vmg_warp_bilinear_fwd   out[n,y,x,:] = bilinear sample of x at (x + flow_x, y + flow_y), border padding.
+ *   vmg_warp_bilinear_bwd   dx_acc (fp32, caller-zeroed, (N,H,W,C)) += scatter of dy; dflow (fp32, caller-zeroed) += d/dflow.
+ *   vmg_warp_nearest_planes advects the tracked-location maps (N,K2,H,W) fp32 with nearest sampling, border padding.
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out, int N, int H, int W, int C, void* stream);
+int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, float* dx_acc, float* dflow, int N, int H,
+                          int W, int C, void* stream);
+int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int N, int K2, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trajectory window attention = LTAM_multi_head.forward_wins without the output projection
+ * (models/trajectory.py:672-774; relative position term cal_pe :534-547).
+ *   q (n,h,w,c); keys[j], vals[j] (n,h,w,c) for key-frame j = 0 (oldest) .. t-1; loc (n,2t,h,w) fp32 tracked pixel
+ *   coordinates (x plane then y plane per key-frame); rpe (heads, wh*ww, wh*ww) fp32; decay (heads) fp32.
+ *   out (n,h,w,c); lse (n,h,w,heads) fp32 log-sum-exp, kept for the backward pass.
+ * Backward: dq (n,h,w,c); dk_acc[j], dv_acc[j] fp32 (n,h,w,c) caller-zeroed accumulators (gradients are scattered to the
+ * gathered source pixels with float atomics); drpe (heads, wq, wq) fp32 accumulated.  heads must be 4.
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_ltam_fwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc, const float* rpe,
+                 const float* decay, void* out, float* lse, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
+                 void* stream);
+int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc, const float* rpe,
+                 const float* decay, const void* out, const float* lse, const void* dout, void* dq, float* const* dk_acc,
+                 float* const* dv_acc, float* drpe, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Live kernel timing (bench.py roofline object): HIP events are recorded on the launch stream around every
  * `stride`-th launch of kernel class `klass` (1 = bf16 conv3x3 144->144, the trajectory-chain kernel, forward
  * and data-gradient alike) until `max_samples` pairs are used.  vmg_prof_end synchronises those events and

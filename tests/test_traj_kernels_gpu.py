@@ -1,0 +1,84 @@
+"""HIP kernels of the trajectory recurrence vs the CPU oracle: flow warp (bilinear/border fwd + bwd, nearest location
+advection) and the fused LTAM window attention (fwd + bwd).  fp32: 1e-5 / 1e-4; bf16 (inputs pre-rounded): 2e-2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from oracle import recipe as R
+    from oracle import vmg_oracle as O
+    from oracle import cases as C
+    from vmg_amd import functional as FH
+    return R, O, C, FH
+
+
+def _q(t, dtype):
+    return t.to(dtype).float() if dtype == torch.bfloat16 else t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 144), (1, 9, 7, 32)])
+def test_flow_warp_bilinear_border_fwd_bwd(dtype, shape):
+    R, O, C, FH = _mods()
+    n, h, w, c = shape
+    x = _q(R.seeded((n, h, w, c), 51), dtype).requires_grad_(True)
+    flow = R.seeded((n, h, w, 2), 52, 3.0).requires_grad_(True)  # incl. far out-of-range samples (border clamp)
+    gy = _q(R.seeded((n, h, w, c), 53), dtype)
+    want = O.flow_warp(x.permute(0, 3, 1, 2), flow, padding="border").permute(0, 2, 3, 1)
+    wdx, wdf = torch.autograd.grad(want, (x, flow), gy)
+    xd = x.detach().cuda().to(dtype).requires_grad_(True)
+    fd = flow.detach().cuda().requires_grad_(True)
+    got = FH.grid_sample_flow(xd, fd, "bilinear", "border")
+    gdx, gdf = torch.autograd.grad(got, (xd, fd), gy.cuda().to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((gdx.float().cpu() - wdx).abs().max()) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, float(wdx.abs().max()))
+    assert float((gdf.cpu() - wdf).abs().max()) <= (1e-3 if dtype == torch.float32 else 3e-2) * max(1.0, float(wdf.abs().max()))
+
+
+def test_location_advection_matches_exactly():
+    """nearest + border on integer-valued location maps must reproduce the oracle bit for bit (index arithmetic)."""
+    R, O, C, FH = _mods()
+    n, k2, h, w = 2, 6, 20, 28
+    loc = C.int_locations(n, k2 // 2, h, w, 54)
+    flow = R.seeded((n, h, w, 2), 55, 2.5)
+    flow[0, :4, :4] = torch.tensor([0.5, -0.5])  # exact half-pixel offsets: round-half-to-even path
+    want = O.flow_warp(loc, flow, mode="nearest", padding="border")
+    got = FH.warp_locations(loc.cuda(), flow.cuda()).cpu()
+    assert torch.equal(got, want)
+
+
+def _ltam_oracle(O, sd, q, keys, vals, loc):
+    n, h, w, c = q.shape
+    return O.ltam_wins(sd, "", q, torch.stack(keys, 1), torch.zeros_like(q), torch.stack(vals, 1), loc, 4, (2, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16, 144), (1, 1, 10, 12, 32), (1, 5, 8, 8, 16)])
+def test_ltam_attention_fwd_bwd(dtype, shape):
+    R, O, C, FH = _mods()
+    n, t, h, w, c = shape
+    q = _q(R.seeded((n, h, w, c), 61), dtype).requires_grad_(True)
+    keys = [_q(R.seeded((n, h, w, c), 62 + j), dtype).requires_grad_(True) for j in range(t)]
+    vals = [_q(R.seeded((n, h, w, c), 72 + j), dtype).requires_grad_(True) for j in range(t)]
+    loc = C.int_locations(n, t, h, w, 82)
+    rpe = R.seeded((4, 4, 4), 83, 0.5).requires_grad_(True)
+    decay = 1 - 2 ** (-5 - torch.arange(3, -1, -1, dtype=torch.float32))
+    sd = {"proj.weight": torch.eye(c), "proj.bias": torch.zeros(c), "relative_pos_encoding": rpe, "decay_v": decay}
+    want = _ltam_oracle(O, sd, q, keys, vals, loc)
+    go = _q(R.seeded((n, h, w, c), 84), dtype)
+    wg = torch.autograd.grad(want, [q, rpe] + keys + vals, go)
+    dev = lambda z: z.detach().cuda().to(dtype).requires_grad_(True)
+    qd, kd, vd = dev(q), [dev(k) for k in keys], [dev(v) for v in vals]
+    rd = rpe.detach().cuda().requires_grad_(True)
+    got = FH.ltam_attention(qd, kd, vd, loc.cuda(), rd, decay.cuda(), 4, 2, 2, (c // 4) ** -0.5)
+    gg = torch.autograd.grad(got, [qd, rd] + kd + vd, go.cuda().to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    gtol = 2e-4 if dtype == torch.float32 else 4e-2
+    names = ["dq", "drpe"] + [f"dk{j}" for j in range(t)] + [f"dv{j}" for j in range(t)]
+    for nm, a, b in zip(names, gg, wg):
+        err = float((a.float().cpu() - b).abs().max())
+        assert err <= gtol * max(1.0, float(b.abs().max())), f"{nm}: {err} vs scale {float(b.abs().max())}"

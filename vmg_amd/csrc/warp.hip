@@ -1,0 +1,189 @@
+// Flow-guided sampling kernels of the trajectory recurrence (models/trajectory.py:71-116, 329-333, 414-417),
+// channels-last, gfx950.  All are HBM-bound gathers: one thread per (pixel, 16-byte channel vector), consecutive
+// lanes walk consecutive channel vectors of a pixel so every corner fetch is a coalesced row segment.
+//
+// Coordinate arithmetic restates flow_warp + F.grid_sample(align_corners=True) step by step in fp32 WITHOUT fused
+// multiply-add contraction (explicit __f*_rn), so that the sampled positions -- and in particular the rounding of the
+// nearest mode and the border clamp -- agree with the reference's CPU path bit for bit:
+//     g  = x + flow_x;  gx = 2*g / max(W-1,1) - 1;  ix = ((gx + 1) / 2) * (W-1)        (same for y)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float unnorm_coord(float pix, float flow, int size) {
+  const float g = __fadd_rn(pix, flow);
+  const float denom = (float)(size - 1 > 1 ? size - 1 : 1);
+  const float gn = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, g), denom), 1.0f);
+  return __fmul_rn(__fdiv_rn(__fadd_rn(gn, 1.0f), 2.0f), (float)(size - 1));
+}
+
+__device__ __forceinline__ float clip_border(float v, int size, float* grad_mult) {
+  // torch clip_coordinates(_set_grad): clamp to [0, size-1]; gradient 0 at or beyond the borders
+  const float hi = (float)(size - 1);
+  if (v <= 0.f) { if (grad_mult) *grad_mult = 0.f; return 0.f; }
+  if (v >= hi) { if (grad_mult) *grad_mult = 0.f; return hi; }
+  if (grad_mult) *grad_mult = 1.f;
+  return v;
+}
+
+template <typename T>
+struct V16 {
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+
+// ------------------------------------------------------------------------------------------ bilinear, border
+template <typename T>
+__global__ __launch_bounds__(256) void warp_bilinear_fwd_kernel(const T* __restrict__ x, const float* __restrict__ flow,
+                                                                T* __restrict__ out, int N, int H, int W, int C) {
+  constexpr int VN = V16<T>::N;
+  const int nvec = C / VN;
+  const long long total = (long long)N * H * W * nvec;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long long pix = i / nvec;
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    const float fx = flow[pix * 2], fy = flow[pix * 2 + 1];
+    const float ix = clip_border(unnorm_coord((float)px, fx, W), W, nullptr);
+    const float iy = clip_border(unnorm_coord((float)py, fy, H), H, nullptr);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;  // weights in ATen's form: nw = (ix_se - ix) * (iy_se - iy), ...
+    const float wnw = (x1f - ix) * (y1f - iy), wne = (ix - x0f) * (y1f - iy), wsw = (x1f - ix) * (iy - y0f), wse = (ix - x0f) * (iy - y0f);
+    const T* base = x + n * H * W * C + v * VN;
+    float acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+    auto corner = [&](int yy, int xx, float wgt) {
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const V16<T> t = *reinterpret_cast<const V16<T>*>(base + ((long long)yy * W + xx) * C);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] += to_f32(t.v[e]) * wgt;
+      }
+    };
+    corner(y0, x0, wnw);
+    corner(y0, x1, wne);
+    corner(y1, x0, wsw);
+    corner(y1, x1, wse);
+    V16<T> o;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o.v[e] = from_f32<T>(acc[e]);
+    *reinterpret_cast<V16<T>*>(out + pix * C + v * VN) = o;
+  }
+}
+
+// backward: dx_acc (fp32, zero-initialised) += scatter of dy; dflow (fp32, zero-initialised) += channel reductions
+template <typename T>
+__global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow,
+                                                                const T* __restrict__ dy, float* __restrict__ dx_acc,
+                                                                float* __restrict__ dflow, int N, int H, int W, int C) {
+  constexpr int VN = V16<T>::N;
+  const int nvec = C / VN;
+  const long long total = (long long)N * H * W * nvec;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long long pix = i / nvec;
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    const float fx = flow[pix * 2], fy = flow[pix * 2 + 1];
+    float gmx, gmy;
+    const float ix = clip_border(unnorm_coord((float)px, fx, W), W, &gmx);
+    const float iy = clip_border(unnorm_coord((float)py, fy, H), H, &gmy);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const float tx = ix - x0f, ty = iy - y0f;
+    const float wnw = (x1f - ix) * (y1f - iy), wne = (ix - x0f) * (y1f - iy), wsw = (x1f - ix) * (iy - y0f), wse = (ix - x0f) * (iy - y0f);
+    const V16<T> g = *reinterpret_cast<const V16<T>*>(dy + pix * C + v * VN);
+    const long long ibase = n * H * W * C + v * VN;
+    float gix = 0.f, giy = 0.f;
+    auto corner = [&](int yy, int xx, float wgt, float dwx, float dwy) {
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const long long off = ibase + ((long long)yy * W + xx) * C;
+        const V16<T> t = *reinterpret_cast<const V16<T>*>(x + off);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          const float ge = to_f32(g.v[e]);
+          atomicAdd(dx_acc + off + e, ge * wgt);
+          const float xv = to_f32(t.v[e]) * ge;
+          gix += xv * dwx;
+          giy += xv * dwy;
+        }
+      }
+    };
+    // d(weight)/d(ix), d(weight)/d(iy) per corner
+    corner(y0, x0, wnw, -(1.f - ty), -(1.f - tx));
+    corner(y0, x1, wne, (1.f - ty), -tx);
+    corner(y1, x0, wsw, -ty, (1.f - tx));
+    corner(y1, x1, wse, ty, tx);
+    // d(ix)/d(flow_x) = (2/(W-1)) * ((W-1)/2) = 1 (0 where the border clamp is active)
+    atomicAdd(dflow + pix * 2, gix * gmx);
+    atomicAdd(dflow + pix * 2 + 1, giy * gmy);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ nearest, border (location maps)
+// loc (N, K2, H, W) fp32 planes (pixel coordinates of tracked points, models/trajectory.py:321,332-333)
+__global__ __launch_bounds__(256) void warp_nearest_planes_kernel(const float* __restrict__ loc, const float* __restrict__ flow,
+                                                                  float* __restrict__ out, int N, int K2, int H, int W) {
+  const long long total = (long long)N * H * W;
+  for (long long pix = blockIdx.x * 256LL + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    const float ix = clip_border(unnorm_coord((float)px, flow[pix * 2], W), W, nullptr);
+    const float iy = clip_border(unnorm_coord((float)py, flow[pix * 2 + 1], H), H, nullptr);
+    const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);  // round half to even, as std::nearbyint in ATen
+    const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+    for (int k = 0; k < K2; ++k) {
+      const long long plane = (n * K2 + k) * H * W;
+      out[plane + (long long)py * W + px] = ok ? loc[plane + (long long)yn * W + xn] : 0.f;
+    }
+  }
+}
+
+int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out, int N, int H, int W, int C, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "warp_fwd: bad dtype");
+  VMG_CHECK(x && flow && out && N > 0 && H > 0 && W > 0 && C > 0, "warp_fwd: bad arguments");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(C % vn == 0, "warp_fwd: C must be a multiple of %d", vn);
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)out) % 16 == 0, "warp_fwd: pointers must be 16-byte aligned");
+  const long long total = (long long)N * H * W * (C / vn);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(warp_bilinear_fwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (bf16*)out, N, H, W, C);
+  else hipLaunchKernelGGL(warp_bilinear_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (float*)out, N, H, W, C);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, float* dx_acc, float* dflow, int N,
+                                     int H, int W, int C, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "warp_bwd: bad dtype");
+  VMG_CHECK(x && flow && dy && dx_acc && dflow && N > 0 && H > 0 && W > 0 && C > 0, "warp_bwd: bad arguments");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(C % vn == 0, "warp_bwd: C must be a multiple of %d", vn);
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)dy) % 16 == 0, "warp_bwd: pointers must be 16-byte aligned");
+  const long long total = (long long)N * H * W * (C / vn);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, dx_acc, dflow, N, H, W, C);
+  else hipLaunchKernelGGL(warp_bilinear_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (const float*)dy, dx_acc, dflow, N, H, W, C);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int N, int K2, int H, int W, void* stream) {
+  VMG_CHECK(loc && flow && out && N > 0 && K2 > 0 && H > 0 && W > 0, "warp_nearest: bad arguments");
+  hipLaunchKernelGGL(warp_nearest_planes_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, loc, flow, out, N, K2, H, W);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}

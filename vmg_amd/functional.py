@@ -330,58 +330,66 @@ def _norm_grid(g, h, w):
     return torch.stack((gx, gy), -1)
 
 
+class _WarpBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow):
+        x = x.contiguous()
+        flow = flow.contiguous()
+        ctx.save_for_backward(x, flow)
+        return K.warp_bilinear_forward(x, flow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, flow = ctx.saved_tensors
+        dx_acc, dflow = K.warp_bilinear_backward(x, flow, dy)
+        return dx_acc.to(x.dtype), dflow
+
+
 def grid_sample_flow(x: torch.Tensor, flow: torch.Tensor, mode: str, padding: str) -> torch.Tensor:
-    """Channels-last flow warp: x (n,h,w,c), flow (n,h,w,2) fp32 pixel offsets (models/trajectory.py:95-116)."""
-    n, h, w, c = x.shape
-    ys, xs = torch.meshgrid(torch.arange(h, device=x.device), torch.arange(w, device=x.device), indexing="ij")
-    grid = _norm_grid(torch.stack((xs, ys), 2).float() + flow, h, w)
-    o = F.grid_sample(x.permute(0, 3, 1, 2), grid.to(x.dtype), mode=mode, padding_mode=padding, align_corners=True)
-    return o.permute(0, 2, 3, 1).contiguous()
+    """Channels-last flow warp: x (n,h,w,c), flow (n,h,w,2) fp32 pixel offsets (models/trajectory.py:95-116).
+    The recurrence only uses bilinear + border (trajectory.py:330, 414)."""
+    if mode != "bilinear" or padding != "border":
+        raise HipError("the HIP flow warp implements bilinear / border (the only combination on the path)")
+    return _WarpBilinear.apply(x, flow.float())
 
 
 def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
-    """Advect the tracked-location maps (n,2k,h,w) with nearest sampling, border padding (trajectory.py:332-333)."""
-    n, k2, h, w = loc.shape
-    ys, xs = torch.meshgrid(torch.arange(h, device=loc.device), torch.arange(w, device=loc.device), indexing="ij")
-    grid = _norm_grid(torch.stack((xs, ys), 2).float() + flow, h, w)
-    return F.grid_sample(loc, grid, mode="nearest", padding_mode="border", align_corners=True)
+    """Advect the tracked-location maps (n,2k,h,w) with nearest sampling, border padding (trajectory.py:332-333).
+    Not differentiable (the reference's nearest sampling has zero gradient w.r.t. grid and the maps are constants)."""
+    return K.warp_nearest_planes(loc.detach(), flow.detach().contiguous())
+
+
+class _LTAM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, loc, rpe, decay_v, cfg, *kv):
+        heads, wh, ww, scale = cfg
+        t = len(kv) // 2
+        keys = [x.contiguous() for x in kv[:t]]
+        vals = [x.contiguous() for x in kv[t:]]
+        q = q.contiguous()
+        loc = loc.contiguous()
+        rpe_c = rpe.detach().contiguous()
+        out, lse = K.ltam_forward(q, keys, vals, loc, rpe_c, decay_v, heads, wh, ww, scale)
+        ctx.cfg = cfg
+        ctx.t = t
+        ctx.save_for_backward(q, loc, rpe_c, decay_v, out, lse, *keys, *vals)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        heads, wh, ww, scale = ctx.cfg
+        t = ctx.t
+        q, loc, rpe, decay_v, out, lse = ctx.saved_tensors[:6]
+        keys = list(ctx.saved_tensors[6:6 + t])
+        vals = list(ctx.saved_tensors[6 + t:])
+        dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale)
+        dt = q.dtype
+        return (dq, None, drpe, None, None, *[g.to(dt) for g in dk], *[g.to(dt) for g in dv])
 
 
 def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):
     """LTAM_multi_head.forward_wins without the output projection (models/trajectory.py:683-774)."""
-    n, h, w, c = q.shape
-    t = len(keys)
-    d = c // heads
-    g = loc.reshape(n, t, 2, h, w).permute(0, 1, 3, 4, 2)
-    grid = _norm_grid(g, h, w).reshape(n * t, h, w, 2)
-
-    def gather(lst):
-        src = torch.stack(lst, 1).reshape(n * t, h, w, c).permute(0, 3, 1, 2)
-        o = F.grid_sample(src, grid.to(src.dtype), mode="nearest", padding_mode="zeros", align_corners=True)
-        return o.permute(0, 2, 3, 1).reshape(n, t, h, w, c)
-
-    v = gather(vals)
-    k = F.normalize(gather(keys).float(), dim=-1)
-    qn = F.normalize(q.float(), dim=-1)
-
-    def windows(z):
-        if z.dim() == 4:
-            z = z[:, None]
-        tt = z.shape[1]
-        z = z.reshape(n, tt, h // wh, wh, w // ww, ww, heads, d)
-        return z.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(n, (h // wh) * (w // ww), heads, tt * wh * ww, d)
-
-    qw, kw, vw = windows(qn), windows(k), windows(v.float())
-    pw = [decay_v.clone()]
-    for _ in range(1, t):
-        pw.append(pw[-1] * decay_v)
-    pw = torch.stack(pw[::-1], 1)  # (head, t): key-frame j (0 = oldest) -> decay^(t-j)
-    qn_ = wh * ww
-    pe = (pw[:, None, :, None] * rpe[:, :, None, :]).reshape(heads, qn_, t * qn_)
-    logits = torch.matmul(qw * scale, kw.transpose(-1, -2)) + pe[None, None]
-    out = torch.matmul(logits.softmax(-1), vw)
-    out = out.reshape(n, h // wh, w // ww, heads, wh, ww, d).permute(0, 1, 4, 2, 5, 3, 6).reshape(n, h, w, c)
-    return out.to(q.dtype).contiguous()
+    return _LTAM.apply(q, loc, rpe, decay_v, (heads, wh, ww, float(scale)), *keys, *vals)
 
 
 def space_to_depth(x: torch.Tensor) -> torch.Tensor:

@@ -271,3 +271,76 @@ def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], 
         da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys[s:s + n]])
         hip.check(l.vmg_conv_wgrad_batched(code, ks, n, xa, da, N, H, W, xps, Cin, dps, Cout, dW.data_ptr(), I_total, o0, i0,
                                            db.data_ptr() if db is not None else None, scale, hip.stream_ptr()), "vmg_conv_wgrad_batched")
+
+
+def _ptrs(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def warp_bilinear_forward(x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+    """x (n,h,w,c) contiguous, flow (n,h,w,2) fp32 contiguous -> bilinear, border padding."""
+    hip.require_cuda(x, flow)
+    n, h, w, c = x.shape
+    if not x.is_contiguous() or flow.dtype != torch.float32 or not flow.is_contiguous() or tuple(flow.shape) != (n, h, w, 2):
+        raise HipError("warp: x must be contiguous (n,h,w,c), flow contiguous fp32 (n,h,w,2)")
+    out = torch.empty_like(x)
+    hip.check(hip.lib().vmg_warp_bilinear_fwd(hip.dtype_code(x.dtype), x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, h, w, c,
+                                              hip.stream_ptr()), "vmg_warp_bilinear_fwd")
+    return out
+
+
+def warp_bilinear_backward(x: torch.Tensor, flow: torch.Tensor, dy: torch.Tensor):
+    n, h, w, c = x.shape
+    dy = dy.contiguous()
+    dx_acc = torch.zeros((n, h, w, c), dtype=torch.float32, device=x.device)
+    dflow = torch.zeros((n, h, w, 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().vmg_warp_bilinear_bwd(hip.dtype_code(x.dtype), x.data_ptr(), flow.data_ptr(), dy.data_ptr(), dx_acc.data_ptr(),
+                                              dflow.data_ptr(), n, h, w, c, hip.stream_ptr()), "vmg_warp_bilinear_bwd")
+    return dx_acc, dflow
+
+
+def warp_nearest_planes(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+    """loc (n,k2,h,w) fp32 planes advected with nearest sampling / border padding."""
+    hip.require_cuda(loc, flow)
+    n, k2, h, w = loc.shape
+    if loc.dtype != torch.float32 or flow.dtype != torch.float32 or not flow.is_contiguous() or tuple(flow.shape) != (n, h, w, 2):
+        raise HipError("warp_nearest_planes: fp32 loc (n,k2,h,w) and flow (n,h,w,2) expected")
+    loc = loc.contiguous()
+    out = torch.empty_like(loc)
+    hip.check(hip.lib().vmg_warp_nearest_planes(loc.data_ptr(), flow.data_ptr(), out.data_ptr(), n, k2, h, w, hip.stream_ptr()),
+              "vmg_warp_nearest_planes")
+    return out
+
+
+def ltam_forward(q, keys, vals, loc, rpe, decay, heads, wh, ww, scale):
+    hip.require_cuda(q, loc, rpe, decay, *keys, *vals)
+    n, h, w, c = q.shape
+    t = len(keys)
+    ts = [q] + list(keys) + list(vals)
+    if any(x.dtype != q.dtype or tuple(x.shape) != (n, h, w, c) or not x.is_contiguous() for x in ts):
+        raise HipError("ltam: q / keys / vals must be contiguous (n,h,w,c) tensors of one dtype")
+    if loc.dtype != torch.float32 or tuple(loc.shape) != (n, 2 * t, h, w) or not loc.is_contiguous():
+        raise HipError(f"ltam: loc must be contiguous fp32 (n,2t,h,w), got {tuple(loc.shape)}")
+    if rpe.dtype != torch.float32 or decay.dtype != torch.float32 or not rpe.is_contiguous():
+        raise HipError("ltam: rpe / decay must be fp32")
+    out = torch.empty_like(q)
+    lse = torch.empty((n, h, w, heads), dtype=torch.float32, device=q.device)
+    hip.check(hip.lib().vmg_ltam_fwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
+                                     decay.data_ptr(), out.data_ptr(), lse.data_ptr(), n, h, w, c, heads, wh, ww, t, scale,
+                                     hip.stream_ptr()), "vmg_ltam_fwd")
+    return out, lse
+
+
+def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale):
+    n, h, w, c = q.shape
+    t = len(keys)
+    dout = dout.contiguous()
+    dq = torch.empty_like(q)
+    acc = torch.zeros((2 * t, n, h, w, c), dtype=torch.float32, device=q.device)
+    drpe = torch.zeros_like(rpe)
+    dk = [acc[j] for j in range(t)]
+    dv = [acc[t + j] for j in range(t)]
+    hip.check(hip.lib().vmg_ltam_bwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
+                                     decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
+                                     drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")
+    return dq, dk, dv, drpe
