@@ -128,7 +128,7 @@ def main():
             avg_s = ms.value / n.value * 1e-3
             flops = K1_FLOPS_PER_PIXEL * B_PER_GPU * H * W  # algorithmic FLOPs of one launch (M = 16384 pixels)
             ach = flops / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,3,1,9> (conv3x3 144->144, fwd+dgrad)",
+            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,3,2,5,deep> (conv3x3 144->144 on 16384 px, fwd+dgrad of the recurrent chains)",
                         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": seen.value // max(1, args.steps),
                         "samples": n.value}

@@ -50,7 +50,7 @@ int vmg_max_lds_bytes(void);
  * Data-gradient packing (transpose_flip = 1): output channels = I[o0 : o0+on), K = O[src_off[0] : +src_ch[0])
  *   with taps mirrored -- conv(dY, pack) is then dX of the forward conv (stride 1, pad KS/2).
  * The packed image is [cout_block][chunk q][co in block][8] elements of `dtype`; its size in bytes is
- * returned by vmg_conv_pack_bytes.  `cout_tiles` (1, 4, 7, 8 or 9) is the number of 16-channel tiles per block and
+ * returned by vmg_conv_pack_bytes.  `cout_tiles` (1, 4, 5, 7, 8 or 9) is the number of 16-channel tiles per block and
  * must be the value later passed to vmg_conv_fwd.
  * ---------------------------------------------------------------------------------------------- */
 int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles);
@@ -94,7 +94,8 @@ typedef struct vmg_conv_desc {
   float slope, alpha;
   int actgrad;
   int pixel_shuffle;
-  int mt; /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
+  int mt;   /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
+  int deep; /* 1 = 3-slot counted-wait weight ring (one workgroup per CU; latency-critical small grids), 0 = 2-slot */
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);

@@ -13,19 +13,40 @@
 //   * MFMA: D[cout 16][pixel 16] += W[cout][k] * X[k][pixel]  (v_mfma_f32_16x16x32_bf16, or 8 x
 //     v_mfma_f32_16x16x4_f32 per k-step for fp32), so a lane ends with 4 consecutive output channels of one
 //     pixel -> 8-byte (bf16) / 16-byte (fp32) channels-last stores.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 constexpr int MAX_ISRC = 32;  // internal sources after channel-block splitting
-constexpr int KSTG = 2;       // k-steps per weight stage
 constexpr int CBMAX = 160;    // max channels per internal source block
+
+// Weight ring geometry.  A stage holds KSTG k-steps of one cout block.  Each source's k-steps are padded (zero
+// weights) to a multiple of kpad(KS), so a stage never straddles two sources and the stage body is a fully unrolled
+// block: all LDS fragment reads of k-step j+1 are issued before the MFMAs of k-step j (two static register sets),
+// which is what lets the compiler emit counted lgkmcnt waits instead of one LDS round trip per MFMA.
+//   bf16 3x3 DEEP : 4 k-steps x 3 slots, COUNTED s_waitcnt vmcnt((RING-2)*IPW): the younger stage stays in flight
+//                   across the barrier (one workgroup per CU; the latency-critical small grids of the recurrence);
+//   bf16 3x3      : 2 k-steps x 2 slots (small LDS footprint: two workgroups per CU hide the stage latency);
+//   1x1 / fp32    : 2 k-steps x 2 slots.
+template <typename T, int KS, bool DEEP>
+struct RingCfg {
+  static constexpr int KSTG = 2, RING = 2;
+};
+template <>
+struct RingCfg<bf16, 3, true> {
+  static constexpr int KSTG = 4, RING = 3;
+};
+constexpr int kpad(int ks) { return ks == 3 ? 4 : 2; }  // per-source k-step padding (multiple of every KSTG in use)
 
 struct ConvK {
   const char* src[MAX_ISRC];
   long long src_ps[MAX_ISRC];
   short src_ch[MAX_ISRC];
-  short src_qp[MAX_ISRC];  // padded chunk count (multiple of 4)
+  short src_qp[MAX_ISRC];  // padded chunk count (multiple of 4 * kpad)
   int src_pixb[MAX_ISRC];  // LDS pixel stride in bytes
   int nsrc;
   const char* wpack;
@@ -42,26 +63,64 @@ struct ConvK {
   int act;
   float slope, alpha;
   int actgrad, ps;
-  int kt;          // total k-steps over all sources
+  int kt;          // total (padded) k-steps over all sources
   int halo_bytes;  // LDS bytes reserved for the halo tile
+  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 2 no MFMA, 4 no halo staging, 8 no store
 };
 
-template <typename T, int KS, int MT, int NTB>
+template <typename T>
+struct Frag;  // 8 consecutive K elements of one row/column of an MFMA operand
+template <>
+struct Frag<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const char* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+};
+template <>
+struct Frag<float> {
+  float4 lo, hi;
+  __device__ __forceinline__ void load(const char* p) {
+    lo = *reinterpret_cast<const float4*>(p);
+    hi = *reinterpret_cast<const float4*>(p + 16);
+  }
+};
+__device__ __forceinline__ f32x4 mma(const Frag<bf16>& w, const Frag<bf16>& x, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, x.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<float>& w, const Frag<float>& x, f32x4 c) {
+  // 8 x v_mfma_f32_16x16x4_f32: lane group g supplies element j of chunk (4*kstep + g) in MFMA j (A and B alike)
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.x, x.lo.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.y, x.lo.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.z, x.lo.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.w, x.lo.w, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.x, x.hi.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.y, x.hi.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.z, x.hi.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.w, x.hi.w, c, 0, 0, 0);
+  return c;
+}
+
+template <typename T, int KS, int MT, int NTB, bool DEEP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
   constexpr int TH = 4 * MT;
   constexpr int TWH = (KS == 3) ? 18 : 16;
   constexpr int THH = (KS == 3) ? TH + 2 : TH;
   constexpr int COB = NTB * 16;
+  constexpr int KSTG = RingCfg<T, KS, DEEP>::KSTG, RING = RingCfg<T, KS, DEEP>::RING;
   constexpr int STAGEB = KSTG * 4 * COB * CB;
+  constexpr int IPW = STAGEB / 4096;  // global_load_lds instructions per wave per stage (when it divides evenly)
+  static_assert(RING == 2 || STAGEB % 4096 == 0, "counted waits need the same number of LDS-DMA instructions in every wave");
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + a.halo_bytes;
+  if (a.dbg & 16) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int cb = blockIdx.y;
+  // 16-channel tiles this block really has (the last block of a layer may be short: its MFMAs are skipped, wave-uniform)
+  const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
   int n = 0, ty = 0, tx = 0;
   long long m0 = 0;
   if (KS == 3) {
@@ -80,112 +139,179 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nstages = (a.kt + KSTG - 1) / KSTG;
+  const int nstages = a.kt / KSTG;
   auto issue_w = [&](int stage) {
-    const char* gsrc = a.wpack + ((long long)cb * a.kt + (long long)stage * KSTG) * (4 * COB * CB);
-    int nks = a.kt - stage * KSTG;
-    if (nks > KSTG) nks = KSTG;
-    const int bytes = nks * 4 * COB * CB;  // multiple of 1024
-    char* dst = wbuf + (stage & 1) * STAGEB;
-    for (int off = wave * 1024; off < bytes; off += 4 * 1024)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off + lane * 16), LDS_PTR(dst + off), 16, 0, 0);
+    if (a.dbg & 1) return;
+    const char* gsrc = a.wpack + ((long long)cb * a.kt + (long long)stage * KSTG) * (4 * COB * CB) + lane * 16;
+    char* dst = wbuf + (stage % RING) * STAGEB;
+    if constexpr (STAGEB % 4096 == 0) {
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int off = (wave + 4 * i) * 1024;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off), LDS_PTR(dst + off), 16, 0, 0);
+      }
+    } else {
+      for (int off = wave * 1024; off < STAGEB; off += 4 * 1024)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off), LDS_PTR(dst + off), 16, 0, 0);
+    }
   };
 
-  issue_w(0);
-  int ksg = 0;  // global k-step
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i)
+    if (i < nstages) issue_w(i);
+  int gst = 0;  // global stage index
   for (int s = 0; s < a.nsrc; ++s) {
     const int ch = a.src_ch[s], pixb = a.src_pixb[s];
     const int CH = ch >> 3;  // chunks per tap
-    const int Q = KK * CH;
-    __syncthreads();  // everyone is done reading the previous halo tile
-    {                 // ---- stage the halo tile of this source
+    __syncthreads();         // everyone is done reading the previous halo tile
+    const bool after_restage = s > 0;  // LDS-DMA of the halo is younger than the weight stages in flight: see the stage wait
+    {
+      // ---- stage the halo tile of this source: (THH rows) x (TWH pixels) x ch channels.
       const char* sp = a.src[s];
       const long long ps_b = a.src_ps[s] * ES;
       const int vpp = ch * ES / 16;  // 16-byte vectors per pixel
-      const int total = THH * TWH * vpp;
-      for (int i = tid; i < total; i += 256) {
-        const int p = i / vpp, v = i - p * vpp;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (KS == 3) {
-          const int r = p / TWH, c = p - r * TWH;
-          const int y = ty * TH + r - 1, x = tx * 16 + c - 1;
-          if (y >= 0 && y < a.H && x >= 0 && x < a.W)
-            val = *reinterpret_cast<const uint4*>(sp + (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16);
-        } else {
-          const long long m = m0 + p;
-          if (m < a.M) val = *reinterpret_cast<const uint4*>(sp + m * ps_b + v * 16);
+      const float inv_vpp = 1.0f / (float)vpp;
+      if (pixb == ch * ES && !(a.dbg & 4)) {
+        // Dense LDS rows: wave w copies rows w, w+4, ... with LDS-DMA (no registers, 1 KiB per instruction); lanes whose
+        // pixel lies outside the image are masked off and write zeros with an ordinary ds_write instead.
+        const int row_vecs = TWH * vpp;
+        for (int r = wave; r < THH; r += 4) {
+          long long rowbase;
+          bool row_ok;
+          int x0;
+          if (KS == 3) {
+            const int y = ty * TH + r - 1;
+            row_ok = y >= 0 && y < a.H;
+            x0 = tx * 16 - 1;
+            rowbase = (((long long)n * a.H + y) * a.W + x0) * ps_b;
+          } else {
+            row_ok = true;
+            x0 = 0;
+            rowbase = (m0 + r * 16) * ps_b;
+          }
+          char* lrow = halo + r * TWH * pixb;
+          for (int i0 = 0; i0 < row_vecs; i0 += 64) {
+            const int vec = i0 + lane;
+            const int p = (int)(((float)vec + 0.5f) * inv_vpp);  // exact for these ranges (vec < 2^16, vpp <= 40)
+            const int v = vec - p * vpp;
+            bool ok = vec < row_vecs && row_ok;
+            if (KS == 3) ok = ok && (x0 + p >= 0) && (x0 + p < a.W);
+            else ok = ok && (m0 + r * 16 + p < a.M);
+            if (ok) __builtin_amdgcn_global_load_lds(GLB_PTR(sp + rowbase + p * ps_b + v * 16), LDS_PTR(lrow + i0 * 16), 16, 0, 0);
+            else if (vec < row_vecs) *reinterpret_cast<uint4*>(lrow + vec * 16) = make_uint4(0, 0, 0, 0);
+          }
         }
-        *reinterpret_cast<uint4*>(halo + p * pixb + v * 16) = val;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        // Padded LDS pixel stride: through registers.  Loads are UNCONDITIONAL (out-of-image lanes read the tensor's
+        // first vector and select zero afterwards): a load behind a per-element branch makes hipcc wait vmcnt(0) per
+        // element; this way a batch of NB loads is in flight before the first LDS write.
+        const int total = (a.dbg & 4) ? 0 : THH * TWH * vpp;
+        constexpr int NB = 8;
+        for (int i0 = tid; i0 < total; i0 += 256 * NB) {
+          uint4 val[NB];
+          int dsto[NB];
+          bool inb[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const int i = i0 + b * 256;
+            const int ic = i < total ? i : total - 1;
+            const int p = (int)(((float)ic + 0.5f) * inv_vpp);
+            const int v = ic - p * vpp;
+            dsto[b] = i < total ? p * pixb + v * 16 : -1;
+            long long goff;
+            if (KS == 3) {
+              const int r = p / TWH, c = p - r * TWH;
+              const int y = ty * TH + r - 1, x = tx * 16 + c - 1;
+              inb[b] = y >= 0 && y < a.H && x >= 0 && x < a.W;
+              goff = (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16;
+            } else {
+              const long long m = m0 + p;
+              inb[b] = m < a.M;
+              goff = m * ps_b + v * 16;
+            }
+            val[b] = *reinterpret_cast<const uint4*>(sp + (inb[b] ? goff : 0));
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if (dsto[b] >= 0) *reinterpret_cast<uint4*>(halo + dsto[b]) = inb[b] ? val[b] : make_uint4(0, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
 
-    // per-lane pixel base offsets in the halo tile
-    int pixoff[MT];
+    // per-lane pixel base addresses in the halo tile
+    const char* pixp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = wave * MT + mt;
-      pixoff[mt] = (KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb;
+      pixp[mt] = halo + ((KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb);
     }
-    // (tap, c8) of this lane group's chunk q = 4*ks + g, advanced incrementally
+    // (tap, c8) of this lane group's chunk q = 4*kstep + g, advanced incrementally
+    // (c8 < CH + 4 <= 5*CH after every "+= 4", so four compares replace the loop: no divergent branches)
+    auto wrap = [&](int& tap_, int& c8_) {
+      const int w = (c8_ >= CH) + (c8_ >= 2 * CH) + (c8_ >= 3 * CH) + (c8_ >= 4 * CH);
+      tap_ += w;
+      c8_ -= w * CH;
+    };
     int tap = 0, c8 = g;
-    while (c8 >= CH) { c8 -= CH; ++tap; }
+    wrap(tap, c8);
 
-    const int nks = a.src_qp[s] >> 2;
-    for (int ks = 0; ks < nks; ++ks, ++ksg) {
-      if (ksg % KSTG == 0) {
-        // stage ksg/KSTG must have landed; all waves are past stage-1's reads -> its buffer is free.
-        // hipcc does NOT drain LDS-DMA (global_load_lds) at __syncthreads(): without this explicit wait the
-        // barrier is a bare s_barrier and waves read the stage before it has landed (seen as run-to-run
-        // differences only when several workgroups share a CU).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int st = ksg / KSTG;
-        if (st + 1 < nstages) issue_w(st + 1);
-      }
-      int t2 = tap, c2 = c8;
-      if (t2 >= KK) { t2 = KK - 1; c2 = CH - 1; }  // zero-weight padding chunk: read any valid address
-      const int ky = (KS == 3) ? t2 / 3 : 0;
-      const int kx = (KS == 3) ? t2 - 3 * ky : 0;
-      const int boff = (ky * TWH + kx) * pixb + c2 * CB;
-      const char* wst = wbuf + ((ksg / KSTG) & 1) * STAGEB + ((ksg % KSTG) * 4 + g) * (COB * CB) + px * CB;
+    const int nst_s = a.src_qp[s] / (4 * KSTG);
+    for (int sl = 0; sl < ((a.dbg & 32) ? 0 : nst_s); ++sl, ++gst) {
+      // Stage gst must have landed, and every wave must be past stage gst-1 before its slot is refilled.  hipcc does
+      // NOT drain LDS-DMA (global_load_lds) at a barrier, so the wait is explicit -- and, with 3 slots, COUNTED: the
+      // younger stage stays in flight across the barrier.  (A bare barrier here gave run-to-run differences whenever
+      // several workgroups shared a CU.)
+      if (RING > 2 && gst + RING - 2 < nstages && !(after_restage && sl == 0))
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * IPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (gst + RING - 1 < nstages) issue_w(gst + RING - 1);
 
-      if constexpr (ES == 2) {
-        bf16x8 xb[MT];
+      // activation-operand offsets of the KSTG k-steps of this stage
+      int boff[KSTG];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xb[mt] = *reinterpret_cast<const bf16x8*>(halo + pixoff[mt] + boff);
-#pragma unroll
-        for (int ct = 0; ct < NTB; ++ct) {
-          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wst + ct * 16 * CB);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[mt], acc[ct][mt], 0, 0, 0);
-        }
-      } else {
-        float xb[MT][8];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float4 lo = *reinterpret_cast<const float4*>(halo + pixoff[mt] + boff);
-          const float4 hi = *reinterpret_cast<const float4*>(halo + pixoff[mt] + boff + 16);
-          xb[mt][0] = lo.x; xb[mt][1] = lo.y; xb[mt][2] = lo.z; xb[mt][3] = lo.w;
-          xb[mt][4] = hi.x; xb[mt][5] = hi.y; xb[mt][6] = hi.z; xb[mt][7] = hi.w;
-        }
-#pragma unroll
-        for (int ct = 0; ct < NTB; ++ct) {
-          const float4 lo = *reinterpret_cast<const float4*>(wst + ct * 16 * CB);
-          const float4 hi = *reinterpret_cast<const float4*>(wst + ct * 16 * CB + 16);
-          const float wa[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              acc[ct][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb[mt][j], acc[ct][mt], 0, 0, 0);
-        }
+      for (int j = 0; j < KSTG; ++j) {
+        int t2 = tap, c2 = c8;
+        if (t2 >= KK) { t2 = KK - 1; c2 = CH - 1; }  // zero-weight padding chunk: read any valid address
+        const int ky = (KS == 3) ? t2 / 3 : 0;
+        const int kx = (KS == 3) ? t2 - 3 * ky : 0;
+        boff[j] = (ky * TWH + kx) * pixb + c2 * CB;
+        c8 += 4;
+        wrap(tap, c8);
       }
-      c8 += 4;
-      while (c8 >= CH) { c8 -= CH; ++tap; }
+      const char* wslot = wbuf + (gst % RING) * STAGEB + g * (COB * CB) + px * CB;
+
+      auto stage_body = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        Frag<T> xf[2][MT], wf[2][NTB];
+        auto load_frags = [&](int j, int set) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xf[set][mt].load(pixp[mt] + boff[j]);
+#pragma unroll
+          for (int ct = 0; ct < NTB; ++ct)
+            if (FULL || ct < nt_real) wf[set][ct].load(wslot + j * (4 * COB * CB) + ct * 16 * CB);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int j = 0; j < KSTG; ++j) {
+          if (j + 1 < KSTG) load_frags(j + 1, (j + 1) & 1);
+#pragma unroll
+          for (int ct = 0; ct < NTB; ++ct)
+            if (FULL || ct < nt_real)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = mma(wf[j & 1][ct], xf[j & 1][mt], acc[ct][mt]);
+        }
+      };
+      if (a.dbg & 2) {
+      } else if (nt_real == NTB) stage_body(std::true_type{});  // wave-uniform: the common, branch-free body
+      else stage_body(std::false_type{});
     }
   }
+  // drain the ring before the epilogue's ordinary loads / exit
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---------------------------------------------------------------------------------------- epilogue
   T* out = reinterpret_cast<T*>(a.out);
@@ -194,6 +320,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   const T* aux = reinterpret_cast<const T*>(a.aux);
   const bool vec_ok = ((a.Cout & 3) == 0) && ((a.out_ps & 3) == 0) && (!res || (a.res_ps & 3) == 0) &&
                       (!aux || (a.aux_ps & 3) == 0);
+  const bool fast = vec_ok && ((a.Cout & 15) == 0);  // every real tile of this block is complete: straight-line path
+  // ReLU / LeakyReLU / none as one select: t > 0 ? t : t * neg
+  const float neg = a.act == VMG_ACT_RELU ? 0.f : (a.act == VMG_ACT_LRELU ? a.slope : 1.f);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     long long pix;
@@ -214,70 +343,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
         n = (int)(t / a.H);
       }
     }
-    if (!valid) continue;
+    if (!valid || (a.dbg & 8)) continue;
+    if (fast) {
 #pragma unroll
-    for (int ct = 0; ct < NTB; ++ct) {
+      for (int ct = 0; ct < NTB; ++ct) {
+        if (ct < nt_real) {
+          const int co0 = cb * COB + ct * 16 + g * 4;
+          float v[4] = {acc[ct][mt][0], acc[ct][mt][1], acc[ct][mt][2], acc[ct][mt][3]};
+          if (a.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + co0);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (out_pre) store4(out_pre + pix * a.out_ps + co0, v);
+          if (a.act == VMG_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]) * a.alpha;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * neg) * a.alpha;
+          }
+          if (aux) {
+            float u[4];
+            load4(aux + pix * a.aux_ps + co0, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = a.actgrad == 3 ? gelu_erf_grad(u[r]) : (u[r] > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+              v[r] *= d;
+            }
+          }
+          if (res) {
+            float u[4];
+            load4(res + pix * a.res_ps + co0, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += u[r];
+          }
+          if (a.ps) {
+            // torch PixelShuffle(2): channel co = c*4 + i*2 + j -> out[n, 2y+i, 2x+j, c]
+            const int c = co0 >> 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const long long op = ((long long)n * (2 * a.H) + (2 * y + (r >> 1))) * (2 * a.W) + (2 * x + (r & 1));
+              out[op * a.out_ps + c] = from_f32<T>(v[r]);
+            }
+          } else {
+            store4(out + pix * a.out_ps + co0, v);
+          }
+        }
+      }
+      continue;
+    }
+    // general path (Cout not a multiple of 16, or unaligned strides): element-wise with bounds checks
+    for (int ct = 0; ct < nt_real; ++ct) {
       const int co0 = cb * COB + ct * 16 + g * 4;
-      if (co0 >= a.Cout) continue;
-      float v[4];
-#pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + r;
-        v[r] = acc[ct][mt][r] + ((a.bias && co < a.Cout) ? a.bias[co] : 0.f);
-      }
-      const bool full = vec_ok && (co0 + 3 < a.Cout);
-      if (out_pre) {
-        if (full) store4(out_pre + pix * a.out_ps + co0, v);
-        else
-          for (int r = 0; r < 4; ++r)
-            if (co0 + r < a.Cout) out_pre[pix * a.out_ps + co0 + r] = from_f32<T>(v[r]);
-      }
+        if (co >= a.Cout) continue;
+        float t = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = v[r];
-        if (a.act == VMG_ACT_RELU) t = fmaxf(t, 0.f);
-        else if (a.act == VMG_ACT_LRELU) t = t > 0.f ? t : t * a.slope;
-        else if (a.act == VMG_ACT_GELU) t = gelu_erf(t);
-        v[r] = t * a.alpha;
-      }
-      if (aux) {
-        float u[4] = {0.f, 0.f, 0.f, 0.f};
-        if (full) load4(aux + pix * a.aux_ps + co0, u);
-        else
-          for (int r = 0; r < 4; ++r)
-            if (co0 + r < a.Cout) u[r] = to_f32(aux[pix * a.aux_ps + co0 + r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float d = 1.f;
-          if (a.actgrad == 1) d = u[r] > 0.f ? 1.f : 0.f;
-          else if (a.actgrad == 2) d = u[r] > 0.f ? 1.f : a.slope;
-          else if (a.actgrad == 3) d = gelu_erf_grad(u[r]);
-          v[r] *= d;
+        for (int c2 = 0; c2 < NTB; ++c2)  // static register index
+          if (c2 == ct) t = r == 0 ? acc[c2][mt][0] : (r == 1 ? acc[c2][mt][1] : (r == 2 ? acc[c2][mt][2] : acc[c2][mt][3]));
+        if (a.bias) t += a.bias[co];
+        if (out_pre) out_pre[pix * a.out_ps + co] = from_f32<T>(t);
+        if (a.act == VMG_ACT_GELU) t = gelu_erf(t) * a.alpha;
+        else t = (t > 0.f ? t : t * neg) * a.alpha;
+        if (aux) {
+          const float u = to_f32(aux[pix * a.aux_ps + co]);
+          t *= a.actgrad == 3 ? gelu_erf_grad(u) : (u > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
         }
-      }
-      if (res) {
-        float u[4] = {0.f, 0.f, 0.f, 0.f};
-        if (full) load4(res + pix * a.res_ps + co0, u);
-        else
-          for (int r = 0; r < 4; ++r)
-            if (co0 + r < a.Cout) u[r] = to_f32(res[pix * a.res_ps + co0 + r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += u[r];
-      }
-      if (a.ps) {
-        // torch PixelShuffle(2): channel co = c*4 + i*2 + j -> out[n, 2y+i, 2x+j, c]
-        const int c = co0 >> 2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (co0 + r >= a.Cout) continue;
-          const long long op = ((long long)n * (2 * a.H) + (2 * y + (r >> 1))) * (2 * a.W) + (2 * x + (r & 1));
-          out[op * a.out_ps + c] = from_f32<T>(v[r]);
+        if (res) t += to_f32(res[pix * a.res_ps + co]);
+        if (a.ps) {
+          const long long op = ((long long)n * (2 * a.H) + (2 * y + ((co & 3) >> 1))) * (2 * a.W) + (2 * x + (co & 1));
+          out[op * a.out_ps + (co >> 2)] = from_f32<T>(t);
+        } else {
+          out[pix * a.out_ps + co] = from_f32<T>(t);
         }
-      } else if (full) {
-        store4(out + pix * a.out_ps + co0, v);
-      } else {
-        for (int r = 0; r < 4; ++r)
-          if (co0 + r < a.Cout) out[pix * a.out_ps + co0 + r] = from_f32<T>(v[r]);
       }
     }
   }
@@ -293,7 +432,7 @@ struct PackK {
 
 template <typename T>
 __global__ void conv_pack_kernel(const PackK p) {
-  // one thread per packed element: [cb][q][co][8]
+  // one thread per packed element: [cb][q][co][8]; each source's chunk range is padded with zeros to src_qp
   const long long total = (long long)p.ncb * p.kt * 4 * p.cob * 8;
   const int KK = p.ks * p.ks;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -318,6 +457,12 @@ __global__ void conv_pack_kernel(const PackK p) {
     }
     reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
   }
+}
+
+// chunks of one source block, padded so that its k-steps are a multiple of kpad(ks) (see RingCfg)
+int padded_chunks(int ks, int ch) {
+  const int q = ks * ks * (ch / 8), gran = 4 * kpad(ks);
+  return (q + gran - 1) / gran * gran;
 }
 
 // internal channel-block splitting: the SAME rule for packing and for the conv call
@@ -366,12 +511,12 @@ int choose_pixb(int ch, int es, int cb) {
   return best;
 }
 
-template <typename T, int KS, int MT, int NTB>
+template <typename T, int KS, int MT, int NTB, bool DEEP>
 int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   constexpr int CB = ElemTraits<T>::CHUNKB;
-  const int lds = k.halo_bytes + 2 * KSTG * 4 * NTB * 16 * CB;
+  const int lds = k.halo_bytes + RingCfg<T, KS, DEEP>::RING * RingCfg<T, KS, DEEP>::KSTG * 4 * NTB * 16 * CB;
   VMG_CHECK(lds <= 160 * 1024, "conv: LDS request %d B exceeds 160 KiB", lds);
-  auto fn = conv_igemm_kernel<T, KS, MT, NTB>;
+  auto fn = conv_igemm_kernel<T, KS, MT, NTB, DEEP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -380,23 +525,24 @@ int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
   // the dominant kernel class of the path: bf16 3x3, one source of 144 channels, 144 outputs (trajectory chains)
-  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, st);
+  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144 && k.M == 16384) && vmg_prof_before(VMG_PROF_CONV3X3, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, k);
   if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();
   return 0;
 }
 
-template <typename T, int KS, int MT>
+template <typename T, int KS, int MT, bool DEEP>
 int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
   switch (ntb) {
-    case 1: return launch_conv<T, KS, MT, 1>(k, ncb, st);
-    case 4: return launch_conv<T, KS, MT, 4>(k, ncb, st);
-    case 7: return launch_conv<T, KS, MT, 7>(k, ncb, st);
-    case 8: return launch_conv<T, KS, MT, 8>(k, ncb, st);
-    case 9: return launch_conv<T, KS, MT, 9>(k, ncb, st);
+    case 1: return launch_conv<T, KS, MT, 1, DEEP>(k, ncb, st);
+    case 4: return launch_conv<T, KS, MT, 4, DEEP>(k, ncb, st);
+    case 5: return launch_conv<T, KS, MT, 5, DEEP>(k, ncb, st);
+    case 7: return launch_conv<T, KS, MT, 7, DEEP>(k, ncb, st);
+    case 8: return launch_conv<T, KS, MT, 8, DEEP>(k, ncb, st);
+    case 9: return launch_conv<T, KS, MT, 9, DEEP>(k, ncb, st);
   }
-  vmg_set_error("conv: cout_tiles must be 1, 4, 7, 8 or 9 (got %d)", ntb);
+  vmg_set_error("conv: cout_tiles must be 1, 4, 5, 7, 8 or 9 (got %d)", ntb);
   return -1;
 }
 
@@ -407,7 +553,7 @@ extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, cons
   const int n = expand_sources(nsrc, nullptr, src_ch, xoff, xch, nullptr);
   if (n < 0 || cout_tiles <= 0) return -1;
   int64_t qp = 0;
-  for (int s = 0; s < n; ++s) qp += (ks * ks * (xch[s] / 8) + 3) / 4 * 4;
+  for (int s = 0; s < n; ++s) qp += padded_chunks(ks, xch[s]);
   const int cob = cout_tiles * 16;
   const int ncb = (on + cob - 1) / cob;
   return (int64_t)ncb * qp * cob * 8 * (dtype == VMG_BF16 ? 2 : 4);
@@ -426,7 +572,7 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   int q = 0;
   for (int s = 0; s < n; ++s) {
     p.src_qoff[s] = (short)q;
-    p.src_qp[s] = (short)((ks * ks * (p.src_ch[s] / 8) + 3) / 4 * 4);
+    p.src_qp[s] = (short)padded_chunks(ks, p.src_ch[s]);
     q += p.src_qp[s];
   }
   // bounds of the slices against the weight tensor
@@ -435,7 +581,7 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   VMG_CHECK(o0 >= 0 && o0 + on <= odim, "conv_pack: output slice out of range");
   p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = ks; p.o0 = o0; p.on = on; p.nsrc = n;
   p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.kt = q / 4;
-  const long long total = (long long)p.ncb * q * p.cob * 8;
+  const long long total = (long long)p.ncb * p.kt * 4 * p.cob * 8;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -475,7 +621,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     VMG_CHECK(((uintptr_t)d->src[par]) % 16 == 0, "conv_fwd: source pointer must be 16-byte aligned");
     k.src[s] = (const char*)d->src[par] + (long long)xoff[s] * es;
     k.src_ps[s] = d->src_ps[par];
-    k.src_qp[s] = (short)((d->ks * d->ks * (k.src_ch[s] / 8) + 3) / 4 * 4);
+    k.src_qp[s] = (short)padded_chunks(d->ks, k.src_ch[s]);
     k.src_pixb[s] = choose_pixb(k.src_ch[s], es, cbytes);
     kt += k.src_qp[s] / 4;
     const int hb = THH * TWH * k.src_pixb[s];
@@ -488,13 +634,23 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.M = M;
   k.tiles_x = cdiv(d->W, 16); k.tiles_y = cdiv(d->H, TH);
   k.act = d->act; k.slope = d->slope; k.alpha = d->alpha; k.actgrad = d->aux ? d->actgrad : 0; k.ps = d->pixel_shuffle;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("VMG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    k.dbg = dbg;
+  }
   k.kt = kt; k.halo_bytes = (halo + 15) & ~15;
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
+  const bool deep = d->deep != 0;
   if (d->dtype == VMG_BF16) {
-    if (d->ks == 3) return mt == 2 ? dispatch_ntb<bf16, 3, 2>(k, ntb, ncb, st) : dispatch_ntb<bf16, 3, 1>(k, ntb, ncb, st);
-    return mt == 2 ? dispatch_ntb<bf16, 1, 2>(k, ntb, ncb, st) : dispatch_ntb<bf16, 1, 1>(k, ntb, ncb, st);
+    if (d->ks == 3) {
+      if (deep) return mt == 2 ? dispatch_ntb<bf16, 3, 2, true>(k, ntb, ncb, st) : dispatch_ntb<bf16, 3, 1, true>(k, ntb, ncb, st);
+      return mt == 2 ? dispatch_ntb<bf16, 3, 2, false>(k, ntb, ncb, st) : dispatch_ntb<bf16, 3, 1, false>(k, ntb, ncb, st);
+    }
+    if (deep) return mt == 2 ? dispatch_ntb<bf16, 1, 2, true>(k, ntb, ncb, st) : dispatch_ntb<bf16, 1, 1, true>(k, ntb, ncb, st);
+    return mt == 2 ? dispatch_ntb<bf16, 1, 2, false>(k, ntb, ncb, st) : dispatch_ntb<bf16, 1, 1, false>(k, ntb, ncb, st);
   }
-  if (d->ks == 3) return dispatch_ntb<float, 3, 1>(k, ntb, ncb, st);
-  return dispatch_ntb<float, 1, 1>(k, ntb, ncb, st);
+  if (d->ks == 3) return dispatch_ntb<float, 3, 1, false>(k, ntb, ncb, st);
+  return dispatch_ntb<float, 1, 1, false>(k, ntb, ncb, st);
 }

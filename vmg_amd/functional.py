@@ -24,11 +24,22 @@ def _pad_to(n: int, m: int = 8) -> int:
     return (n + m - 1) // m * m
 
 
+def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
+    """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3):
+    the 144-channel 3x3 convs run best as 128-pixel x 80-channel workgroups (two cout blocks); when that grid is at
+    most ~one workgroup per CU (the latency-critical recurrent convs, M = 16 384) the 3-slot counted-wait weight ring wins,
+    on large grids the small-LDS 2-slot ring (two workgroups per CU) does."""
+    if dtype == torch.bfloat16 and ks == 3 and cout == 144:
+        blocks = (M + 127) // 128 * 2
+        return 5, 2, 1 if blocks <= 320 else 0
+    return None, 1, 0
+
+
 def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
-           i0: int = 0, on: Optional[int] = None) -> K.PackedConv:
+           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None) -> K.PackedConv:
     """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
     needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8)."""
-    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on)
+    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles)
     ver = weight._version
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
@@ -53,12 +64,12 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
                 off += c
             w = torch.cat(parts, 1)
             src_ch = [_pad_to(c) for c in src_ch]
-        pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch))
+        pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles)
     elif kind == "dgrad":
         on = I - i0 if on is None else on
         if O % 8:
             w = torch.cat([w, w.new_zeros(_pad_to(O) - O, *w.shape[1:])], 0)
-        pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True)
+        pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
     else:
         raise HipError(kind)
     _PACK_CACHE[key] = (ver, pw, weight)
@@ -159,10 +170,11 @@ class _Conv2d(torch.autograd.Function):
         dt = srcs[0].dtype
         src_ch = [s.shape[-1] for s in srcs]
         srcs_p = [_pad_channels(s) for s in srcs]
-        pw = packed(weight, dt, "fwd", src_ch)
+        tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt)
+        pw = packed(weight, dt, "fwd", src_ch, tiles=tiles)
         need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
         out, pre = K.conv_forward(srcs_p, pw, bias, N, H, W, act=act, slope=slope, alpha=alpha, res=res,
-                                  pixel_shuffle=pixel_shuffle, want_pre=need_pre)
+                                  pixel_shuffle=pixel_shuffle, want_pre=need_pre, mt=mt, deep=deep)
         ctx.cfg = cfg
         ctx.src_ch = src_ch
         ctx.src_shapes = [tuple(t.shape) for t in srcs]
@@ -200,8 +212,9 @@ class _Conv2d(torch.autograd.Function):
         dpre_p = _pad_channels(dpre)
         for i, c in enumerate(ctx.src_ch):
             if ctx.needs_input_grad[4 + i]:
-                pw = packed(weight, dpre.dtype, "dgrad", None, off, c)
-                dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W)
+                tiles, mt, deep = choose_tiling(N * H * W, c, ks, dpre.dtype)
+                pw = packed(weight, dpre.dtype, "dgrad", None, off, c, tiles=tiles)
+                dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep)
                 d_srcs.append(dx.reshape(ctx.src_shapes[i]))
             else:
                 d_srcs.append(None)

@@ -33,7 +33,7 @@ class ConvDesc(ctypes.Structure):
         ("res", c_void_p), ("res_ps", c_int64),
         ("aux", c_void_p), ("aux_ps", c_int64),
         ("act", c_int), ("slope", c_float), ("alpha", c_float),
-        ("actgrad", c_int), ("pixel_shuffle", c_int), ("mt", c_int),
+        ("actgrad", c_int), ("pixel_shuffle", c_int), ("mt", c_int), ("deep", c_int),
     ]
 
 

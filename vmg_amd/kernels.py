@@ -45,7 +45,7 @@ class PackedConv:
 
 def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None,
                      src_off: Optional[Sequence[int]] = None, o0: int = 0, on: Optional[int] = None,
-                     transpose_flip: bool = False, out: Optional[torch.Tensor] = None) -> PackedConv:
+                     transpose_flip: bool = False, out: Optional[torch.Tensor] = None, cout_tiles: Optional[int] = None) -> PackedConv:
     """w: fp32 (O, I, KS, KS) or (O, I).  Forward pack: K slices = src_off/src_ch over I, outputs O[o0:o0+on).
     Data-gradient pack (transpose_flip): outputs I[o0:o0+on), K = O[src_off[0]:+src_ch[0])."""
     hip.require_cuda(w)
@@ -67,7 +67,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
             acc += c
     if on is None:
         on = odim - o0
-    tiles = cout_tiles_for(on)
+    tiles = cout_tiles if cout_tiles else cout_tiles_for(on)
     code = hip.dtype_code(dtype)
     l = hip.lib()
     nbytes = l.vmg_conv_pack_bytes(code, ks, on, len(src_ch), _intarr(src_ch), tiles)
@@ -100,7 +100,7 @@ def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[to
                  act: int = hip.ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
                  aux: Optional[torch.Tensor] = None, actgrad: int = 0, pixel_shuffle: bool = False,
                  out: Optional[torch.Tensor] = None, out_pre: Optional[torch.Tensor] = None, want_pre: bool = False,
-                 mt: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                 mt: int = 0, deep: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Runs vmg_conv_fwd.  srcs: channels-last tensors (..., C_s) covering N*H*W pixels each (channel slices of
     wider tensors are fine).  Returns (out, out_pre)."""
     if len(srcs) != len(pw.src_ch):
@@ -152,7 +152,7 @@ def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[to
             raise HipError(f"{name}: shape {tuple(t.shape)} does not match conv output")
         setattr(d, name, t.data_ptr())
         setattr(d, name + "_ps", _pix_stride(t))
-    d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt = act, slope, alpha, actgrad, int(pixel_shuffle), mt
+    d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt, d.deep = act, slope, alpha, actgrad, int(pixel_shuffle), mt, deep
     hip.check(hip.lib().vmg_conv_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_conv_fwd")
     return out, out_pre
 
