@@ -306,22 +306,35 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
         dv[d] += pr * to_f32(graw[d]);
       }
     }
-    // normalisation Jacobian of the key row, then scatter to the gather source
+    // normalisation Jacobian of the key row; then the rows are scattered to their gather sources.  The scatter goes
+    // through LDS so that lanes run along CHANNELS: each atomic wave-instruction adds 64 consecutive floats (256
+    // contiguous bytes = the full-rate shape of global float atomics here; a lane-per-head-slice scatter strides the
+    // lanes by D floats and was ~10x slower).  The K/V tiles of this key-frame are dead by now and are reused as the
+    // fp32 row buffer [64][c] (kt and vt are contiguous: 2 tiles hold 64*c floats for bf16 and fp32 alike).
     {
       float nd = 0.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) nd += kn[d] * dkn[d];
       nd = quad_sum(nd);
-      const int s = sidx[p];
-      if (s >= 0 && inside) {
-        const float inv = 1.f / knorm[p];
-        float* dk = a.dk_acc[j] + (img + s) * c + hd * D;
-        float* dvp = a.dv_acc[j] + (img + s) * c + hd * D;
+      const float inv = 1.f / knorm[p];
+      float* rowbuf = reinterpret_cast<float*>(kt);
+      __syncthreads();  // every thread is done reading kt / vt of this key-frame
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          atomicAdd(dk + d, (dkn[d] - kn[d] * nd) * inv);
-          atomicAdd(dvp + d, dv[d]);
-        }
+      for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = (dkn[d] - kn[d] * nd) * inv;
+      __syncthreads();
+      for (int i = tid; i < LT_PIX * c; i += 256) {
+        const int pp = i / c, ch = i - pp * c;
+        const int sp = sidx[pp];
+        if (sp >= 0 && selfidx[pp] >= 0) atomicAdd(a.dk_acc[j] + (img + sp) * c + ch, rowbuf[i]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = dv[d];
+      __syncthreads();
+      for (int i = tid; i < LT_PIX * c; i += 256) {
+        const int pp = i / c, ch = i - pp * c;
+        const int sp = sidx[pp];
+        if (sp >= 0 && selfidx[pp] >= 0) atomicAdd(a.dv_acc[j] + (img + sp) * c + ch, rowbuf[i]);
       }
     }
   }

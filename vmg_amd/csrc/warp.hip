@@ -74,17 +74,17 @@ __global__ __launch_bounds__(256) void warp_bilinear_fwd_kernel(const T* __restr
   }
 }
 
-// backward: dx_acc (fp32, zero-initialised) += scatter of dy; dflow (fp32, zero-initialised) += channel reductions
+// backward: dx_acc (fp32, zero-initialised) += scatter of dy; dflow = channel reductions.
+// One WAVE per output pixel, lanes along channels: every atomic wave-instruction adds 64 consecutive floats (256
+// contiguous bytes, the full-rate shape of global float atomics on this chip; a lane-per-vector mapping strides the
+// lanes by 32 B and ran 10x slower), and the flow gradient is a wave reduction written without atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow,
                                                                 const T* __restrict__ dy, float* __restrict__ dx_acc,
                                                                 float* __restrict__ dflow, int N, int H, int W, int C) {
-  constexpr int VN = V16<T>::N;
-  const int nvec = C / VN;
-  const long long total = (long long)N * H * W * nvec;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int v = (int)(i % nvec);
-    const long long pix = i / nvec;
+  const int lane = threadIdx.x & 63;
+  const long long npix = (long long)N * H * W;
+  for (long long pix = blockIdx.x * 4LL + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
     const int px = (int)(pix % W);
     const int py = (int)((pix / W) % H);
     const long long n = pix / ((long long)W * H);
@@ -97,31 +97,26 @@ __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restr
     const float x1f = x0f + 1.f, y1f = y0f + 1.f;
     const float tx = ix - x0f, ty = iy - y0f;
     const float wnw = (x1f - ix) * (y1f - iy), wne = (ix - x0f) * (y1f - iy), wsw = (x1f - ix) * (iy - y0f), wse = (ix - x0f) * (iy - y0f);
-    const V16<T> g = *reinterpret_cast<const V16<T>*>(dy + pix * C + v * VN);
-    const long long ibase = n * H * W * C + v * VN;
+    const bool vnw = y0 >= 0 && y0 < H && x0 >= 0 && x0 < W, vne = y0 >= 0 && y0 < H && x1 >= 0 && x1 < W;
+    const bool vsw = y1 >= 0 && y1 < H && x0 >= 0 && x0 < W, vse = y1 >= 0 && y1 < H && x1 >= 0 && x1 < W;
+    const long long ib = n * H * W * C;
+    const long long onw = ib + ((long long)y0 * W + x0) * C, one = ib + ((long long)y0 * W + x1) * C;
+    const long long osw = ib + ((long long)y1 * W + x0) * C, ose = ib + ((long long)y1 * W + x1) * C;
     float gix = 0.f, giy = 0.f;
-    auto corner = [&](int yy, int xx, float wgt, float dwx, float dwy) {
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const long long off = ibase + ((long long)yy * W + xx) * C;
-        const V16<T> t = *reinterpret_cast<const V16<T>*>(x + off);
-#pragma unroll
-        for (int e = 0; e < VN; ++e) {
-          const float ge = to_f32(g.v[e]);
-          atomicAdd(dx_acc + off + e, ge * wgt);
-          const float xv = to_f32(t.v[e]) * ge;
-          gix += xv * dwx;
-          giy += xv * dwy;
-        }
-      }
-    };
-    // d(weight)/d(ix), d(weight)/d(iy) per corner
-    corner(y0, x0, wnw, -(1.f - ty), -(1.f - tx));
-    corner(y0, x1, wne, (1.f - ty), -tx);
-    corner(y1, x0, wsw, -ty, (1.f - tx));
-    corner(y1, x1, wse, ty, tx);
+    for (int c = lane; c < C; c += 64) {
+      const float g = to_f32(dy[pix * C + c]);
+      if (vnw) { atomicAdd(dx_acc + onw + c, g * wnw); const float xv = to_f32(x[onw + c]) * g; gix -= xv * (1.f - ty); giy -= xv * (1.f - tx); }
+      if (vne) { atomicAdd(dx_acc + one + c, g * wne); const float xv = to_f32(x[one + c]) * g; gix += xv * (1.f - ty); giy -= xv * tx; }
+      if (vsw) { atomicAdd(dx_acc + osw + c, g * wsw); const float xv = to_f32(x[osw + c]) * g; gix -= xv * ty; giy += xv * (1.f - tx); }
+      if (vse) { atomicAdd(dx_acc + ose + c, g * wse); const float xv = to_f32(x[ose + c]) * g; gix += xv * ty; giy += xv * tx; }
+    }
+    gix = wave_sum(gix);
+    giy = wave_sum(giy);
     // d(ix)/d(flow_x) = (2/(W-1)) * ((W-1)/2) = 1 (0 where the border clamp is active)
-    atomicAdd(dflow + pix * 2, gix * gmx);
-    atomicAdd(dflow + pix * 2 + 1, giy * gmy);
+    if (lane == 0) {
+      dflow[pix * 2] = gix * gmx;
+      dflow[pix * 2 + 1] = giy * gmy;
+    }
   }
 }
 
@@ -171,9 +166,8 @@ extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "warp_bwd: bad dtype");
   VMG_CHECK(x && flow && dy && dx_acc && dflow && N > 0 && H > 0 && W > 0 && C > 0, "warp_bwd: bad arguments");
   const int vn = dtype == VMG_BF16 ? 8 : 4;
-  VMG_CHECK(C % vn == 0, "warp_bwd: C must be a multiple of %d", vn);
-  VMG_CHECK(((uintptr_t)x | (uintptr_t)dy) % 16 == 0, "warp_bwd: pointers must be 16-byte aligned");
-  const long long total = (long long)N * H * W * (C / vn);
+  (void)vn;
+  const long long total = (long long)N * H * W * 64;  // one wave per pixel
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VMG_BF16) hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, dx_acc, dflow, N, H, W, C);
   else hipLaunchKernelGGL(warp_bilinear_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (const float*)dy, dx_acc, dflow, N, H, W, C);
