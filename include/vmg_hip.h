@@ -118,6 +118,14 @@ int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void* const* x, 
                            int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db,
                            float scale, void* stream);
 
+/* The same with a caller-provided workspace (vmg_conv_wgrad_ws_bytes() bytes, reusable across calls on one stream): bf16 3x3
+ * gradients then take the large-tile kernel (144 x 48 x 9 outputs per workgroup, partial slabs + ordered reduction: bitwise
+ * reproducible, no atomics); every other case falls through to vmg_conv_wgrad_batched. */
+int64_t vmg_conv_wgrad_ws_bytes(void);
+int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
+                              int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db,
+                              float scale, void* ws, int64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound, one pass, 16-byte vectors).
  *

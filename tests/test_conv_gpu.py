@@ -197,3 +197,33 @@ def test_conv_repeatable_under_load(shape):
     for _ in range(10):
         again = K.conv_forward([x], pw, None, N, H, W, mt=mt)[0]
         assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 40, 144, 144, 3), (1, 9, 70, 64, 64, 2), (1, 16, 32, 288, 144, 1), (2, 8, 8, 144, 288, 4),
+                                   (1, 64, 64, 144, 144, 14)])
+def test_conv_wgrad_batched_large_tile(shape):
+    """bf16 3x3 batched weight gradient = the large-tile kernel (LDS-DMA tiles, slabs + ordered reduction); the result
+    must equal the sum over pairs of autograd gradients, accumulate into dW/db, and be bitwise reproducible."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, P = shape
+    dt = torch.bfloat16
+    xs = [R.seeded((N, H, W, Ci), 40 + p) for p in range(P)]
+    dys = [R.seeded((N, H, W, Co), 60 + p) for p in range(P)]
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    gw, gb = torch.zeros_like(w), torch.zeros_like(b)
+    for x, dy in zip(xs, dys):
+        g1, g2 = torch.autograd.grad(O.conv_nhwc(_q(x, dt), w, b, 1), (w, b), _q(dy, dt))
+        gw += g1
+        gb += g2
+    init_w, init_b = R.seeded((Co, Ci, 3, 3), 80), R.seeded((Co,), 81)
+    xd, dd = [x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys]
+    outs = []
+    for rep in range(2):
+        dW, db = init_w.clone().cuda(), init_b.clone().cuda()
+        K.conv_wgrad_batched(xd, dd, dW, db, 3, N, H, W, scale=0.5)
+        outs.append((dW.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])  # no atomics: reproducible
+    scale = max(1.0, float(gw.abs().max()))
+    assert float((outs[0][0] - (init_w + 0.5 * gw)).abs().max()) <= 2e-3 * scale
+    assert float((outs[0][1] - (init_b + 0.5 * gb)).abs().max()) <= 2e-3 * max(1.0, float(gb.abs().max()))

@@ -323,3 +323,206 @@ extern "C" int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void*
                                       float* db, float scale, void* stream) {
   return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
 }
+
+// =====================================================================================================
+// v2 (bf16, 3x3): large output tile, shared LDS tiles, slab reduction.
+//
+// The v1 kernel above gives every workgroup a 48 x 16 x 9 output tile, so dY is re-read 9x and X 3x from L2/HBM (1.2 GB
+// for the batched gradient of one recurrent conv) and the float-atomic epilogue scales with the number of K splits.
+// v2: a workgroup of 9 waves owns ALL 144 output channels x 48 input channels x 9 taps; wave (cg, it) accumulates
+// co-tiles 3cg..3cg+2 x ci-tile it x 9 taps = 27 MFMA tiles.  Per 32-pixel K unit the dY tile [32][144] and the X
+// tile [3][34][48] are filled by LDS-DMA (global_load_lds, per-lane source, lane-linear destination; out-of-image
+// lanes read a zero buffer, so every wave issues the same 3 DMA instructions per unit and the wait can be COUNTED),
+// double-buffered, two barriers per unit.  dY is then read 3x, X once.  Partial results go to per-split slabs in the
+// accumulator's native layout with coalesced float4 stores; a second kernel sums the slabs in a fixed order (bitwise
+// reproducible, unlike atomics) and adds them into the OIHW gradient.  The bias gradient is one more MFMA per co-tile
+// against a ones operand.
+// =====================================================================================================
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_buf[64];  // 256 zero bytes: DMA source for out-of-image lanes
+
+struct Wgrad2K {
+  const char* x[WG_MAX_PAIRS];
+  const char* dy[WG_MAX_PAIRS];
+  int npairs;
+  long long Upair, U;
+  long long x_ps, dy_ps;
+  int Cin, Cout;
+  float* slab;       // [S][ciblk][coblk][9 waves][28 tiles][64][4]
+  int N, H, W, SEG, S;
+  int has_bias;
+};
+
+constexpr int W2_WAVES = 9, W2_THREADS = 576;
+constexpr int W2_DYC = 144, W2_XC = 48, W2_XR = 3, W2_XW = 34;
+constexpr int W2_DY_BYTES = 32 * W2_DYC * 2;                // 9216
+constexpr int W2_X_BYTES = W2_XR * W2_XW * W2_XC * 2;       // 9792
+constexpr int W2_BUF = W2_DY_BYTES + W2_X_BYTES;            // 19008 (16-byte multiple)
+constexpr int W2_XVEC = W2_XR * W2_XW * (W2_XC / 8);        // 612 vectors in the X tile
+constexpr int W2_XVW = (W2_XVEC + W2_WAVES - 1) / W2_WAVES;  // 68 per wave -> 2 DMA instructions (64 + 4 lanes)
+constexpr int W2_TILES = 28;                                // 27 accumulator tiles + 1 bias tile per wave
+constexpr long long W2_WG_FLOATS = (long long)W2_WAVES * W2_TILES * 256;
+
+__global__ __launch_bounds__(W2_THREADS) void conv_wgrad2_kernel(const Wgrad2K a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = wave / 3, it = wave - cg * 3;
+  const int ob = blockIdx.x * W2_DYC, ib = blockIdx.y * W2_XC;
+  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
+
+  f32x4 acc[3][9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  auto issue = [&](long long ug, int buf) {
+    const int pair = (int)(ug / a.Upair);
+    const long long u = ug - (long long)pair * a.Upair;
+    const int seg = (int)(u % a.SEG);
+    const long long r = u / a.SEG;
+    const int y = (int)(r % a.H), n = (int)(r / a.H);
+    const int x0 = seg * 32;
+    char* dyt = smem + buf * W2_BUF;
+    char* xt = dyt + W2_DY_BYTES;
+    {  // dY tile: 576 vectors, one per thread: pixel p, 8-channel vector v
+      const int p = tid / 18, v = tid - p * 18;
+      const int c = ob + v * 8;
+      const bool ok = (x0 + p < a.W) && (c + 8 <= a.Cout);
+      const char* src = ok ? a.dy[pair] + ((((long long)n * a.H + y) * a.W + x0 + p) * a.dy_ps + c) * 2 : zsrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dyt + wave * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // X tile: this wave's share of 68 vectors in two instructions
+      const int k = 64 * i + lane;
+      const int vec = W2_XVW * wave + k;
+      if (k < W2_XVW && vec < W2_XVEC) {
+        const int p = vec / 6, v = vec - p * 6;
+        const int rr = p / W2_XW, col = p - rr * W2_XW;
+        const int yy = y + rr - 1, xx = x0 + col - 1;
+        const int c = ib + v * 8;
+        const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && (c + 8 <= a.Cin);
+        const char* src = ok ? a.x[pair] + ((((long long)n * a.H + yy) * a.W + xx) * a.x_ps + c) * 2 : zsrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(xt + (W2_XVW * wave + 64 * i) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  if (u_lo < u_hi) issue(u_lo, 0);
+  for (long long u = u_lo; u < u_hi; ++u) {
+    const int buf = (int)((u - u_lo) & 1);
+    if (u + 1 < u_hi) {
+      issue(u + 1, buf ^ 1);  // its buffer was last read in iteration u-1; everyone passed that iteration's closing barrier
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u landed; unit u+1 (3 instructions per wave) stays in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* dyt = smem + buf * W2_BUF;
+    const char* xt = dyt + W2_DY_BYTES;
+    bf16x8 af[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) af[c] = tr_frag(dyt, W2_DYC * 2, 0, (cg * 3 + c) * 16, lane);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ky = t / 3, kx = t - 3 * ky;
+      const bf16x8 bfg = tr_frag(xt + ky * W2_XW * (W2_XC * 2), W2_XC * 2, kx, it * 16, lane);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg, acc[c][t], 0, 0, 0);
+    }
+    if (a.has_bias && it == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all waves are done reading this buffer
+    asm volatile("" ::: "memory");
+  }
+  // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
+  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W2_WAVES + wave) * (W2_TILES * 256);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(sl + ((c * 9 + t) * 64 + lane) * 4) = acc[c][t];
+  // bias tile: rows 4g..4g+3 of co-tile c live in lanes with (lane & 15) == 0; pack the three co-tiles into one tile slot
+  if (a.has_bias && it == 0 && blockIdx.y == 0) {
+    f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15;
+    if (l15 < 3) pack = l15 == 0 ? accb[0] : (l15 == 1 ? accb[1] : accb[2]);  // column l15 of D is as good as column 0
+    *reinterpret_cast<f32x4*>(sl + (27 * 64 + lane) * 4) = pack;
+  }
+}
+
+// sums the S slabs in order and adds into dW / db
+__global__ __launch_bounds__(256) void conv_wgrad2_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
+                                                                 float* __restrict__ dW, int I_total, int o0, int i0,
+                                                                 float* __restrict__ db, float scale) {
+  const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_s; i += (long long)gridDim.x * 256) {
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += slab[s * per_s + i];
+    // decode i -> (ciblk, coblk, wave, tile, lane, r)
+    const int r = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    long long q = i >> 8;
+    const int tile = (int)(q % W2_TILES);
+    q /= W2_TILES;
+    const int wave = (int)(q % W2_WAVES);
+    q /= W2_WAVES;
+    const int coblk = (int)(q % gx), ciblk = (int)(q / gx);
+    const int cg = wave / 3, it = wave - cg * 3;
+    const int g = lane >> 4, l15 = lane & 15;
+    if (tile < 27) {
+      const int c = tile / 9, t = tile - c * 9;
+      const int co = coblk * W2_DYC + (cg * 3 + c) * 16 + 4 * g + r;
+      const int ci = ciblk * W2_XC + it * 16 + l15;
+      if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 9 + t] += sum * scale;
+    } else if (db && it == 0 && ciblk == 0 && l15 < 3) {
+      const int co = coblk * W2_DYC + (cg * 3 + l15) * 16 + 4 * g + r;
+      if (co < Cout) db[o0 + co] += sum * scale;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W2_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~83 MB)
+
+extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
+                                         int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0,
+                                         float* db, float scale, void* ws, int64_t ws_bytes, void* stream) {
+  // the large-tile path needs bf16, 3x3, 16-byte aligned 8-channel vectors; anything else takes the v1 kernel
+  bool ok = ws && dtype == VMG_BF16 && ks == 3 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
+            (Cin % 8 == 0) && (Cout % 8 == 0);
+  for (int p = 0; ok && p < npairs; ++p) ok = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
+  if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
+  VMG_CHECK(N > 0 && H > 0 && W > 0 && dW && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad arguments");
+  Wgrad2K k;
+  memset(&k, 0, sizeof(k));
+  for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
+  k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout;
+  k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32);
+  k.Upair = (long long)N * H * k.SEG; k.U = k.Upair * npairs;
+  k.has_bias = db != nullptr;
+  const int gx = cdiv(Cout, W2_DYC), gy = cdiv(Cin, W2_XC);
+  long long S = 256 / ((long long)gx * gy);
+  if (S > k.U / 8) S = k.U / 8;
+  if (S < 1) S = 1;
+  const long long need = S * gx * gy * W2_WG_FLOATS * 4;
+  if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
+  k.S = (int)S; k.slab = (float*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 2 * W2_BUF, st, k);
+  VMG_LAUNCH_CHECK();
+  const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
+  const int rb = (int)(cdiv64(per_s, 256) > 2048 ? 2048 : cdiv64(per_s, 256));
+  hipLaunchKernelGGL(conv_wgrad2_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}

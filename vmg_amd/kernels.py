@@ -265,12 +265,27 @@ def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], 
         raise HipError(f"gradient tensor {tuple(dW.shape)} does not match conv (ks={ks}, Cout={Cout}+{o0}, Cin={Cin}+{i0})")
     code = hip.dtype_code(x0.dtype)
     l = hip.lib()
+    ws = _wgrad_workspace(dW.device)
     for s in range(0, len(xs), 16):
         n = min(16, len(xs) - s)
         xa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xs[s:s + n]])
         da = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dys[s:s + n]])
-        hip.check(l.vmg_conv_wgrad_batched(code, ks, n, xa, da, N, H, W, xps, Cin, dps, Cout, dW.data_ptr(), I_total, o0, i0,
-                                           db.data_ptr() if db is not None else None, scale, hip.stream_ptr()), "vmg_conv_wgrad_batched")
+        hip.check(l.vmg_conv_wgrad_batched_ws(code, ks, n, xa, da, N, H, W, xps, Cin, dps, Cout, dW.data_ptr(), I_total, o0, i0,
+                                              db.data_ptr() if db is not None else None, scale, ws.data_ptr(), ws.numel(),
+                                              hip.stream_ptr()), "vmg_conv_wgrad_batched_ws")
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device) -> torch.Tensor:
+    """Slab workspace of the large-tile weight-gradient kernel: allocated once per device, reused (calls are stream-ordered)."""
+    key = str(device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(int(hip.lib().vmg_conv_wgrad_ws_bytes()), dtype=torch.uint8, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
 
 
 def _ptrs(ts):
