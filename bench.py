@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
+                    "HIP-event roofline needs eager launches, so eager is the default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +104,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = args.graph and not distributed
+    mode = "eager"
+    if use_graph:
+        try:
+            step.capture(lrs, hrs, warmup=max(1, args.warmup))
+            mode = "hipgraph"
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print("[bench] graph capture failed (%s: %s); running eagerly" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+            step.graph = None
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(lrs, hrs)
     barrier()
@@ -128,7 +140,7 @@ def main():
             avg_s = ms.value / n.value * 1e-3
             flops = K1_FLOPS_PER_PIXEL * B_PER_GPU * H * W  # algorithmic FLOPs of one launch (M = 16384 pixels)
             ach = flops / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,3,2,5,deep> (conv3x3 144->144 on 16384 px, fwd+dgrad of the recurrent chains)",
+            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,KS=3,MT=1,NTB=5> (conv3x3 144->144 on 16384 px, fwd+dgrad of the recurrent chains)",
                         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": seen.value // max(1, args.steps),
                         "samples": n.value}
@@ -144,7 +156,7 @@ def main():
         "dtype": "bf16", "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
         "config": {"workload": "VMG-REDS-few_levels train step, per-GPU batch 4x7x3x64x64 -> 4x SR (BASELINE configs[1])",
                    "global_batch": world * B_PER_GPU, "frames_per_clip": T, "lr_size": [H, W], "parallelism": f"dp{world}",
-                   "per_gpu_value": round(value / world, 3),
+                   "per_gpu_value": round(value / world, 3), "launch": mode,
                    "model_tflops": round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2), "loss": float(loss)},
         "roofline": roofline,
     }

@@ -5,11 +5,18 @@
 //   * spatial tile of TH = 4*MT rows x 16 columns (KS = 3) or 64*MT consecutive rows of the (M, C) matrix
 //     (KS = 1); wave w owns MT 16-pixel rows of it; blockIdx.y selects a block of NTB*16 output channels.
 //   * K order = for each source tensor (a channel block of <= 160 channels; virtual concat = several sources):
-//       for tap (ky,kx): for 8-channel chunk c8.   One k-step = 4 chunks = 32 K values (one chunk per 16-lane
-//       group of the MFMA operand).  Each source's chunk count is padded to a multiple of 4 with zero weights.
-//   * the source's halo tile ((TH+2) x 18 pixels, all channels of the block) is staged once in LDS; the
-//     activation operand of every (tap, chunk) is a plain 16-byte LDS read at (pixel + tap offset).
-//   * packed weights stream through a 2-deep LDS ring, 2 k-steps per stage, with global_load_lds (16 B/lane).
+//       for 32-channel block cbk: for tap (ky, kx).  One k-step = (cbk, tap) = 32 K values: lane group g of the MFMA
+//       operand holds the 8-channel chunk 4*cbk + g.  The tap -- hence the LDS offset of the activation operand -- is
+//       WAVE-UNIFORM per k-step (with one wave per SIMD every per-lane VALU instruction costs >= 4 cycles, and the
+//       per-lane (tap, chunk) bookkeeping of a (tap, chunk)-ordered K cost as much as the MFMAs it fed).
+//   * a STAGE = one (cbk, ky) row of 3 taps (3x3) or 2 channel blocks (1x1): a fully unrolled block in which the LDS
+//     fragment reads of k-step j+1 are issued before the MFMAs of k-step j (two static register sets).
+//   * the source's halo tile ((TH+2) x 18 pixels, all channels of the block) is staged once in LDS by LDS-DMA rows;
+//     the activation operand of every k-step is a plain 16-byte LDS read at (pixel + tap offset).
+//   * packed weights stream through an LDS ring of stages filled by global_load_lds (16 B/lane, 1 KiB per
+//     instruction).  Stage images are padded to a multiple of 4 KiB so every wave issues the same number IPW of
+//     instructions and "stage s has landed" is a COUNTED s_waitcnt vmcnt((RING-2)*IPW): with 3 slots the younger
+//     stage stays in flight across the barrier.  hipcc does NOT drain LDS-DMA at __syncthreads(): the wait is explicit.
 //   * MFMA: D[cout 16][pixel 16] += W[cout][k] * X[k][pixel]  (v_mfma_f32_16x16x32_bf16, or 8 x
 //     v_mfma_f32_16x16x4_f32 per k-step for fp32), so a lane ends with 4 consecutive output channels of one
 //     pixel -> 8-byte (bf16) / 16-byte (fp32) channels-last stores.
@@ -24,29 +31,21 @@ namespace {
 constexpr int MAX_ISRC = 32;  // internal sources after channel-block splitting
 constexpr int CBMAX = 160;    // max channels per internal source block
 
-// Weight ring geometry.  A stage holds KSTG k-steps of one cout block.  Each source's k-steps are padded (zero
-// weights) to a multiple of kpad(KS), so a stage never straddles two sources and the stage body is a fully unrolled
-// block: all LDS fragment reads of k-step j+1 are issued before the MFMAs of k-step j (two static register sets),
-// which is what lets the compiler emit counted lgkmcnt waits instead of one LDS round trip per MFMA.
-//   bf16 3x3 DEEP : 4 k-steps x 3 slots, COUNTED s_waitcnt vmcnt((RING-2)*IPW): the younger stage stays in flight
-//                   across the barrier (one workgroup per CU; the latency-critical small grids of the recurrence);
-//   bf16 3x3      : 2 k-steps x 2 slots (small LDS footprint: two workgroups per CU hide the stage latency);
-//   1x1 / fp32    : 2 k-steps x 2 slots.
-template <typename T, int KS, bool DEEP>
-struct RingCfg {
-  static constexpr int KSTG = 2, RING = 2;
-};
-template <>
-struct RingCfg<bf16, 3, true> {
-  static constexpr int KSTG = 4, RING = 3;
-};
-constexpr int kpad(int ks) { return ks == 3 ? 4 : 2; }  // per-source k-step padding (multiple of every KSTG in use)
+// ---- stage geometry shared by the packer, the host launcher and the kernel
+__host__ __device__ constexpr int kstg(int ks) { return ks == 3 ? 3 : 2; }  // k-steps per stage
+__host__ __device__ constexpr int stage_bytes(int ks, int ntb, int cb) { return kstg(ks) * 4 * ntb * 16 * cb; }
+__host__ __device__ constexpr int stage_stride(int ks, int ntb, int cb) { return (stage_bytes(ks, ntb, cb) + 4095) / 4096 * 4096; }
+// stages of one source block of `ch` channels: 32-channel blocks x 3 tap rows (3x3) or pairs of blocks (1x1)
+__host__ __device__ inline int stages_of(int ks, int ch) {
+  const int nb = (ch / 8 + 3) / 4;
+  return ks == 3 ? 3 * nb : (nb + 1) / 2;
+}
 
 struct ConvK {
   const char* src[MAX_ISRC];
   long long src_ps[MAX_ISRC];
   short src_ch[MAX_ISRC];
-  short src_qp[MAX_ISRC];  // padded chunk count (multiple of 4 * kpad)
+  short src_nst[MAX_ISRC];  // stages of this source
   int src_pixb[MAX_ISRC];  // LDS pixel stride in bytes
   int nsrc;
   const char* wpack;
@@ -63,9 +62,9 @@ struct ConvK {
   int act;
   float slope, alpha;
   int actgrad, ps;
-  int kt;          // total (padded) k-steps over all sources
+  int nstages;     // total stages over all sources
   int halo_bytes;  // LDS bytes reserved for the halo tile
-  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 2 no MFMA, 4 no halo staging, 8 no store
+  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop
 };
 
 template <typename T>
@@ -106,10 +105,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   constexpr int TWH = (KS == 3) ? 18 : 16;
   constexpr int THH = (KS == 3) ? TH + 2 : TH;
   constexpr int COB = NTB * 16;
-  constexpr int KSTG = RingCfg<T, KS, DEEP>::KSTG, RING = RingCfg<T, KS, DEEP>::RING;
-  constexpr int STAGEB = KSTG * 4 * COB * CB;
-  constexpr int IPW = STAGEB / 4096;  // global_load_lds instructions per wave per stage (when it divides evenly)
-  static_assert(RING == 2 || STAGEB % 4096 == 0, "counted waits need the same number of LDS-DMA instructions in every wave");
+  constexpr int KSTG = kstg(KS), RING = DEEP ? 3 : 2;
+  constexpr int SS = stage_stride(KS, NTB, CB);  // stage image size in LDS and in the packed weights
+  constexpr int IPW = SS / 4096;                 // global_load_lds instructions per wave per stage
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -139,21 +137,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nstages = a.kt / KSTG;
+  const int nstages = a.nstages;
+  const char* wsrc = a.wpack + (long long)cb * nstages * SS + (wave * 1024 + lane * 16);
   auto issue_w = [&](int stage) {
     if (a.dbg & 1) return;
-    const char* gsrc = a.wpack + ((long long)cb * a.kt + (long long)stage * KSTG) * (4 * COB * CB) + lane * 16;
-    char* dst = wbuf + (stage % RING) * STAGEB;
-    if constexpr (STAGEB % 4096 == 0) {
+    const char* gsrc = wsrc + (long long)stage * SS;
+    char* dst = wbuf + (stage % RING) * SS + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < IPW; ++i) {
-        const int off = (wave + 4 * i) * 1024;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off), LDS_PTR(dst + off), 16, 0, 0);
-      }
-    } else {
-      for (int off = wave * 1024; off < STAGEB; off += 4 * 1024)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + off), LDS_PTR(dst + off), 16, 0, 0);
-    }
+    for (int i = 0; i < IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + i * 4096), LDS_PTR(dst + i * 4096), 16, 0, 0);
   };
 
 #pragma unroll
@@ -162,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   int gst = 0;  // global stage index
   for (int s = 0; s < a.nsrc; ++s) {
     const int ch = a.src_ch[s], pixb = a.src_pixb[s];
-    const int CH = ch >> 3;  // chunks per tap
+    const int CH = ch >> 3;  // 8-channel chunks of this source
     __syncthreads();         // everyone is done reading the previous halo tile
     const bool after_restage = s > 0;  // LDS-DMA of the halo is younger than the weight stages in flight: see the stage wait
     {
@@ -247,22 +238,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
       const int row = wave * MT + mt;
       pixp[mt] = halo + ((KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb);
     }
-    // (tap, c8) of this lane group's chunk q = 4*kstep + g, advanced incrementally
-    // (c8 < CH + 4 <= 5*CH after every "+= 4", so four compares replace the loop: no divergent branches)
-    auto wrap = [&](int& tap_, int& c8_) {
-      const int w = (c8_ >= CH) + (c8_ >= 2 * CH) + (c8_ >= 3 * CH) + (c8_ >= 4 * CH);
-      tap_ += w;
-      c8_ -= w * CH;
-    };
-    int tap = 0, c8 = g;
-    wrap(tap, c8);
 
-    const int nst_s = a.src_qp[s] / (4 * KSTG);
-    for (int sl = 0; sl < ((a.dbg & 32) ? 0 : nst_s); ++sl, ++gst) {
-      // Stage gst must have landed, and every wave must be past stage gst-1 before its slot is refilled.  hipcc does
-      // NOT drain LDS-DMA (global_load_lds) at a barrier, so the wait is explicit -- and, with 3 slots, COUNTED: the
-      // younger stage stays in flight across the barrier.  (A bare barrier here gave run-to-run differences whenever
-      // several workgroups shared a CU.)
+    const int nst_s = ((a.dbg & 32) ? 0 : a.src_nst[s]);
+    int cbk = 0, ky = 0;  // 3x3: stage = (channel block cbk, tap row ky); 1x1: stage = channel blocks 2*sl, 2*sl+1
+    for (int sl = 0; sl < nst_s; ++sl, ++gst) {
+      // Stage gst must have landed, and every wave must be past stage gst-1 before its slot is refilled.
       if (RING > 2 && gst + RING - 2 < nstages && !(after_restage && sl == 0))
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * IPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -270,44 +250,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
       asm volatile("" ::: "memory");
       if (gst + RING - 1 < nstages) issue_w(gst + RING - 1);
 
-      // activation-operand offsets of the KSTG k-steps of this stage
+      // activation-operand offsets of the KSTG k-steps (zero-weight padding chunks read the last real chunk)
       int boff[KSTG];
+      if (KS == 3) {
+        const int base = ky * (TWH * pixb) + min(4 * cbk + g, CH - 1) * CB;
+#pragma unroll
+        for (int j = 0; j < KSTG; ++j) boff[j] = base + j * pixb;
+        if (++ky == 3) { ky = 0; ++cbk; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KSTG; ++j) boff[j] = min(4 * (2 * sl + j) + g, CH - 1) * CB;
+      }
+      const char* wslot = wbuf + (gst % RING) * SS + g * (COB * CB) + px * CB;
+
+      // ONE straight-line body: every tile of the block is computed (padding tiles of a short last block have zero
+      // weights).  Two variants of this body -- e.g. a branch-free one and one that skips padding tiles -- make hipcc
+      // merge the accumulators of both paths with v_accvgpr_mov shuffles around every MFMA (4 copies per MFMA measured).
+      Frag<T> xf[2][MT], wf[2][NTB];
+      auto load_frags = [&](int j, int set) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[set][mt].load(pixp[mt] + boff[j]);
+#pragma unroll
+        for (int ct = 0; ct < NTB; ++ct) wf[set][ct].load(wslot + j * (4 * COB * CB) + ct * 16 * CB);
+      };
+      load_frags(0, 0);
 #pragma unroll
       for (int j = 0; j < KSTG; ++j) {
-        int t2 = tap, c2 = c8;
-        if (t2 >= KK) { t2 = KK - 1; c2 = CH - 1; }  // zero-weight padding chunk: read any valid address
-        const int ky = (KS == 3) ? t2 / 3 : 0;
-        const int kx = (KS == 3) ? t2 - 3 * ky : 0;
-        boff[j] = (ky * TWH + kx) * pixb + c2 * CB;
-        c8 += 4;
-        wrap(tap, c8);
+        if (j + 1 < KSTG) load_frags(j + 1, (j + 1) & 1);
+#pragma unroll
+        for (int ct = 0; ct < NTB; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = mma(wf[j & 1][ct], xf[j & 1][mt], acc[ct][mt]);
       }
-      const char* wslot = wbuf + (gst % RING) * STAGEB + g * (COB * CB) + px * CB;
-
-      auto stage_body = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        Frag<T> xf[2][MT], wf[2][NTB];
-        auto load_frags = [&](int j, int set) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) xf[set][mt].load(pixp[mt] + boff[j]);
-#pragma unroll
-          for (int ct = 0; ct < NTB; ++ct)
-            if (FULL || ct < nt_real) wf[set][ct].load(wslot + j * (4 * COB * CB) + ct * 16 * CB);
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int j = 0; j < KSTG; ++j) {
-          if (j + 1 < KSTG) load_frags(j + 1, (j + 1) & 1);
-#pragma unroll
-          for (int ct = 0; ct < NTB; ++ct)
-            if (FULL || ct < nt_real)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = mma(wf[j & 1][ct], xf[j & 1][mt], acc[ct][mt]);
-        }
-      };
-      if (a.dbg & 2) {
-      } else if (nt_real == NTB) stage_body(std::true_type{});  // wave-uniform: the common, branch-free body
-      else stage_body(std::false_type{});
     }
   }
   // drain the ring before the epilogue's ordinary loads / exit
@@ -426,43 +400,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 struct PackK {
   const float* w;
   char* out;
-  int O, I, ks, o0, on, nsrc, transpose_flip, cob, ncb, kt;
-  short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_qoff[MAX_ISRC], src_qp[MAX_ISRC];
+  int O, I, ks, o0, on, nsrc, transpose_flip, cob, ncb, nstages, ss_elems;  // ss_elems = stage stride in elements
+  short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_st0[MAX_ISRC], src_nst[MAX_ISRC];
 };
 
 template <typename T>
 __global__ void conv_pack_kernel(const PackK p) {
-  // one thread per packed element: [cb][q][co][8]; each source's chunk range is padded with zeros to src_qp
-  const long long total = (long long)p.ncb * p.kt * 4 * p.cob * 8;
-  const int KK = p.ks * p.ks;
+  // one thread per packed element of [cout block][stage][stage image]; a stage image is [k-step j][chunk g][co][8]
+  // followed by zero padding up to the 4-KiB-aligned stage stride
+  const long long total = (long long)p.ncb * p.nstages * p.ss_elems;
+  const int KK = p.ks * p.ks, KSTG = kstg(p.ks);
+  const int body = KSTG * 4 * p.cob * 8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long long r = i >> 3;
-    const int co = (int)(r % p.cob);
-    r /= p.cob;
-    const int q = (int)(r % (p.kt * 4));
-    const int cb = (int)(r / (p.kt * 4));
-    int s = 0;
-    while (s + 1 < p.nsrc && q >= p.src_qoff[s + 1]) ++s;
-    const int ql = q - p.src_qoff[s];
-    const int CH = p.src_ch[s] >> 3;
-    const int col = cb * p.cob + co;  // output channel within [0, on)
+    const int within = (int)(i % p.ss_elems);
+    long long r = i / p.ss_elems;
+    const int stage = (int)(r % p.nstages);
+    const int cb = (int)(r / p.nstages);
     float v = 0.f;
-    if (ql < KK * CH && col < p.on) {
-      const int tap = ql / CH, c = (ql - tap * CH) * 8 + e;
-      const int kc = p.src_off[s] + c;  // K-side channel
-      const int oc = p.o0 + col;        // output-side channel
-      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
-      else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
+    if (within < body) {
+      const int e = within & 7;
+      int t = within >> 3;
+      const int co = t % p.cob;
+      t /= p.cob;
+      const int g = t & 3, j = t >> 2;
+      int s = 0;
+      while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
+      const int sl = stage - p.src_st0[s];
+      const int CH = p.src_ch[s] >> 3;
+      int tap, q;
+      if (p.ks == 3) { const int cbk = sl / 3, ky = sl - 3 * cbk; tap = ky * 3 + j; q = 4 * cbk + g; }
+      else { tap = 0; q = 4 * (2 * sl + j) + g; }
+      const int col = cb * p.cob + co;  // output channel within [0, on)
+      if (q < CH && col < p.on) {
+        const int kc = p.src_off[s] + q * 8 + e;  // K-side channel
+        const int oc = p.o0 + col;                // output-side channel
+        if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
+        else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
+      }
     }
     reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
   }
-}
-
-// chunks of one source block, padded so that its k-steps are a multiple of kpad(ks) (see RingCfg)
-int padded_chunks(int ks, int ch) {
-  const int q = ks * ks * (ch / 8), gran = 4 * kpad(ks);
-  return (q + gran - 1) / gran * gran;
 }
 
 // internal channel-block splitting: the SAME rule for packing and for the conv call
@@ -514,7 +491,7 @@ int choose_pixb(int ch, int es, int cb) {
 template <typename T, int KS, int MT, int NTB, bool DEEP>
 int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   constexpr int CB = ElemTraits<T>::CHUNKB;
-  const int lds = k.halo_bytes + RingCfg<T, KS, DEEP>::RING * RingCfg<T, KS, DEEP>::KSTG * 4 * NTB * 16 * CB;
+  const int lds = k.halo_bytes + (DEEP ? 3 : 2) * stage_stride(KS, NTB, CB);
   VMG_CHECK(lds <= 160 * 1024, "conv: LDS request %d B exceeds 160 KiB", lds);
   auto fn = conv_igemm_kernel<T, KS, MT, NTB, DEEP>;
   static bool attr_set = false;
@@ -551,12 +528,12 @@ int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
 extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles) {
   short xoff[MAX_ISRC], xch[MAX_ISRC];
   const int n = expand_sources(nsrc, nullptr, src_ch, xoff, xch, nullptr);
-  if (n < 0 || cout_tiles <= 0) return -1;
-  int64_t qp = 0;
-  for (int s = 0; s < n; ++s) qp += padded_chunks(ks, xch[s]);
+  if (n < 0 || cout_tiles <= 0 || (ks != 1 && ks != 3)) return -1;
+  int64_t nst = 0;
+  for (int s = 0; s < n; ++s) nst += stages_of(ks, xch[s]);
   const int cob = cout_tiles * 16;
   const int ncb = (on + cob - 1) / cob;
-  return (int64_t)ncb * qp * cob * 8 * (dtype == VMG_BF16 ? 2 : 4);
+  return (int64_t)ncb * nst * stage_stride(ks, cout_tiles, dtype == VMG_BF16 ? 16 : 32);
 }
 
 extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
@@ -569,19 +546,21 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   memset(&p, 0, sizeof(p));
   const int n = expand_sources(nsrc, src_off, src_ch, p.src_off, p.src_ch, nullptr);
   VMG_CHECK(n > 0, "conv_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
-  int q = 0;
+  int st = 0;
   for (int s = 0; s < n; ++s) {
-    p.src_qoff[s] = (short)q;
-    p.src_qp[s] = (short)padded_chunks(ks, p.src_ch[s]);
-    q += p.src_qp[s];
+    p.src_st0[s] = (short)st;
+    p.src_nst[s] = (short)stages_of(ks, p.src_ch[s]);
+    st += p.src_nst[s];
   }
   // bounds of the slices against the weight tensor
   const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
   for (int s = 0; s < n; ++s) VMG_CHECK(p.src_off[s] >= 0 && p.src_off[s] + p.src_ch[s] <= kdim, "conv_pack: K slice out of range");
   VMG_CHECK(o0 >= 0 && o0 + on <= odim, "conv_pack: output slice out of range");
   p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = ks; p.o0 = o0; p.on = on; p.nsrc = n;
-  p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.kt = q / 4;
-  const long long total = (long long)p.ncb * p.kt * 4 * p.cob * 8;
+  p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.nstages = st;
+  const int es = dtype == VMG_BF16 ? 2 : 4;
+  p.ss_elems = stage_stride(ks, cout_tiles, es * 8) / es;
+  const long long total = (long long)p.ncb * p.nstages * p.ss_elems;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -621,9 +600,9 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     VMG_CHECK(((uintptr_t)d->src[par]) % 16 == 0, "conv_fwd: source pointer must be 16-byte aligned");
     k.src[s] = (const char*)d->src[par] + (long long)xoff[s] * es;
     k.src_ps[s] = d->src_ps[par];
-    k.src_qp[s] = (short)padded_chunks(d->ks, k.src_ch[s]);
+    k.src_nst[s] = (short)stages_of(d->ks, k.src_ch[s]);
     k.src_pixb[s] = choose_pixb(k.src_ch[s], es, cbytes);
-    kt += k.src_qp[s] / 4;
+    kt += k.src_nst[s];
     const int hb = THH * TWH * k.src_pixb[s];
     if (hb > halo) halo = hb;
   }
@@ -639,7 +618,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     if (dbg < 0) { const char* e = getenv("VMG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
     k.dbg = dbg;
   }
-  k.kt = kt; k.halo_bytes = (halo + 15) & ~15;
+  k.nstages = kt; k.halo_bytes = (halo + 15) & ~15;
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
   const bool deep = d->deep != 0;

@@ -25,13 +25,11 @@ def _pad_to(n: int, m: int = 8) -> int:
 
 
 def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
-    """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3):
-    the 144-channel 3x3 convs run best as 128-pixel x 80-channel workgroups (two cout blocks); when that grid is at
-    most ~one workgroup per CU (the latency-critical recurrent convs, M = 16 384) the 3-slot counted-wait weight ring wins,
-    on large grids the small-LDS 2-slot ring (two workgroups per CU) does."""
+    """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3, kernel
+    durations): the 144-channel 3x3 convs run best as 64-pixel x 80-channel workgroups (two cout blocks) with the 2-slot
+    weight ring, whose small LDS footprint puts two workgroups on a CU: 16.8 us at M = 16 384, 100 us at M = 114 688."""
     if dtype == torch.bfloat16 and ks == 3 and cout == 144:
-        blocks = (M + 127) // 128 * 2
-        return 5, 2, 1 if blocks <= 320 else 0
+        return 5, 1, 0
     return None, 1, 0
 
 

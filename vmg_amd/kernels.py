@@ -18,16 +18,16 @@ def _intarr(v: Sequence[int]):
     return (ctypes.c_int * len(v))(*[int(x) for x in v])
 
 
-def cout_tiles_for(cout: int) -> int:
-    """16-channel tiles per workgroup: 9 covers C = 144/288/576 exactly, 7 covers 112/224/448, 8 covers 128/256;
-    otherwise the candidate with the least padding."""
+def cout_tiles_for(cout: int, dtype: torch.dtype = torch.bfloat16) -> int:
+    """16-channel tiles per workgroup: 9 covers C = 144/288/576 exactly, 7 covers 112/224/448, 8 covers 128/256; otherwise
+    the candidate with the least padding.  fp32 (the parity path) has twice the bytes per stage: at most 5 tiles."""
     t = (cout + 15) // 16
     if t <= 1:
         return 1
     if t <= 4:
         return 4
-    best, waste = 9, None
-    for cand in (9, 8, 7):
+    best, waste = None, None
+    for cand in ((5, 4) if dtype == torch.float32 else (9, 8, 7, 5)):
         w = (t + cand - 1) // cand * cand - t
         if waste is None or w < waste:
             best, waste = cand, w
@@ -67,7 +67,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
             acc += c
     if on is None:
         on = odim - o0
-    tiles = cout_tiles if cout_tiles else cout_tiles_for(on)
+    tiles = cout_tiles if cout_tiles else cout_tiles_for(on, dtype)
     code = hip.dtype_code(dtype)
     l = hip.lib()
     nbytes = l.vmg_conv_pack_bytes(code, ks, on, len(src_ch), _intarr(src_ch), tiles)

@@ -188,7 +188,10 @@ class TrainStep:
             wd_ids = {id(p) for p in model.mlp_wd_param}
             groups[1]["params"] = [p for p in rest if id(p) not in wd_ids]
             groups.append({"params": [p for p in rest if id(p) in wd_ids], "weight_decay": weight_decay})
-        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0, fused=next(model.parameters()).is_cuda)
+        on_gpu = next(model.parameters()).is_cuda
+        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0, fused=on_gpu, capturable=on_gpu)
+        self.graph = None
+        self._static = None
         self.loss_args = dict(eps=eps_loss, aux=aux, aux_ratio=aux_ratio)
         self.reducer = GradBucketReducer(model.parameters(), bucket_bytes) if distributed else None
         if distributed:
@@ -199,7 +202,42 @@ class TrainStep:
         from . import functional as FH
         FH.flush_deferred_wgrads()
 
+    def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2):
+        """Capture one whole training step (forward, loss, backward, deferred weight gradients, AdamW) into a hipGraph.
+
+        The step launches ~8 000 small kernels; replaying them from a graph removes the Python / launch overhead that
+        otherwise rivals the GPU time.  Every weight pack must be recorded INSIDE the graph (weights change on each
+        replay), hence the pack cache is cleared first.  Single-GPU only: the bucketed all-reduce stays eager."""
+        if self.reducer is not None:
+            raise RuntimeError("graph capture is for the single-GPU step; the distributed step runs eagerly")
+        from . import functional as FH
+        self._static = (lrs.clone(), hrs.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        FH.clear_pack_cache()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._loss = self._eager(*self._static)
+        return self
+
+    def replay(self, lrs: Optional[torch.Tensor] = None, hrs: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if lrs is not None:
+            self._static[0].copy_(lrs)
+            self._static[1].copy_(hrs)
+        self.graph.replay()
+        return self._loss
+
     def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
+        if self.graph is not None:
+            return self.replay(lrs, hrs)
+        return self._eager(lrs, hrs)
+
+    def _eager(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
         out = self.model(lrs)
         loss = charbonnier_edge_loss(out.float(), hrs.float(), **self.loss_args)
         loss.backward()
