@@ -147,6 +147,22 @@ int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mea
                       float* dw, float* db, int64_t M, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * TAB token-mixer tail (models/function.py:542-558 channel attention, :791-802 branch re-weighting + tanh gate).
+ * Tensors are (G, R, C) channels-last views (G groups of R rows); per-(group, channel) quantities are fp32.
+ *   vmg_group_reduce     mode 0: out[g,c] += scale * sum_r (a [+ b + c3])   mode 1: out[g,c] += scale * sum_r a*b   (out caller-zeroed)
+ *   vmg_tab_elementwise  op 0 CA_FWD   o0 = (p0 * coef[g,c] + p1) * s
+ *                        op 1 CA_BWD   o0 = p0 * s * coef[g,c] + add[g,c];  o1 = p0 * s
+ *                        op 2 MIX_FWD  o0 = p0*coef[g,c,0] + p1*coef[g,c,1] + p2*coef[g,c,2]
+ *                        op 3 MIX_BWD  o_k = p0 * coef[g,c,k] + add[g,c]   (k = 0,1,2)
+ *                        op 4 GATE_FWD o0 = (p0 + p1) * tanh(p1)
+ *                        op 5 GATE_BWD p0 = dy, p1 = x, p2 = y:  o0 = dy*tanh(y);  o1 = dy*(tanh(y) + (x+y)*(1 - tanh(y)^2))
+ * ---------------------------------------------------------------------------------------------- */
+int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode, float scale,
+                     void* stream);
+int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add, float s,
+                        void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Flow-guided sampling of the trajectory recurrence (models/trajectory.py:71-116 flow_warp, :329-333, :414-417).
  * flow: (N,H,W,2) fp32 pixel offsets (x then y); coordinates follow flow_warp + F.grid_sample(align_corners=True).
  *   vmg_warp_bilinear_fwd   out[n,y,x,:] = bilinear sample of x at (x + flow_x, y + flow_y), border padding.

@@ -1,0 +1,67 @@
+"""HIP kernels of the TAB mixer tail (channel attention, branch re-weighting, tanh gate) vs the oracle, fwd + bwd."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _q(t, dtype):
+    return t.to(dtype).float() if dtype == torch.bfloat16 else t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rcab_matches_oracle_fwd_bwd(dtype):
+    """RCAB = 2 convs + channel attention + residual; compares the product module against oracle.rcab (autograd)."""
+    from oracle import cases as C, recipe as R, vmg_oracle as O
+    from vmg_amd.model import RCAB
+    from vmg_amd import functional as FH
+    case = C.CASES["rcab_c144"]
+    shapes, _ = C.load_fixture("tests/golden/rcab_c144.npz")
+    sd = C.case_state_dict(case, shapes)
+    x = _q(case["inputs"]()["x"], dtype)
+    osd = {k: (_q(v, dtype) if k.endswith("weight") and v.dim() == 4 and v.shape[-1] == 3 else v.clone()).requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.rcab(osd, "", xo)
+    go = _q(R.seeded(tuple(x.shape), 91), dtype)
+    wg = torch.autograd.grad(want, [xo] + [osd[k] for k in sorted(osd)], go)
+    m = RCAB(144).cuda()
+    m.load_state_dict(sd)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    got = m(xd)
+    got.backward(go.cuda().to(dtype))
+    FH.flush_deferred_wgrads()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= tol * max(1.0, float(wg[0].abs().max()))
+    params = dict(m.named_parameters())
+    for k, gw in zip(sorted(osd), wg[1:]):
+        err = float((params[k].grad.cpu() - gw).abs().max())
+        assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reweight_mix_and_gate_fwd_bwd(dtype):
+    from oracle import recipe as R
+    from vmg_amd import functional as FH
+    import torch.nn.functional as F
+    B, T, H, W, C = 2, 3, 10, 12, 144
+    hs = [_q(R.seeded((B, T, H, W, C), 100 + i), dtype).requires_grad_(True) for i in range(3)]
+    fc1w, fc1b = R.seeded((36, C), 104, C ** -0.5).requires_grad_(True), R.seeded((36,), 105, 0.1).requires_grad_(True)
+    fc2w, fc2b = R.seeded((3 * C, 36), 106, 36 ** -0.5).requires_grad_(True), R.seeded((3 * C,), 107, 0.1).requires_grad_(True)
+    x = _q(R.seeded((B, T, H, W, C), 108), dtype).requires_grad_(True)
+    # oracle: models/function.py:791-793, 801-802
+    a = (hs[0] + hs[1] + hs[2]).mean((1, 2, 3))
+    a = F.linear(F.gelu(F.linear(a, fc1w, fc1b)), fc2w, fc2b).reshape(B, C, 3).softmax(-1)[:, None, None, None]
+    y = hs[0] * a[..., 0] + hs[1] * a[..., 1] + hs[2] * a[..., 2]
+    want = (x + y) * torch.tanh(y)
+    go = _q(R.seeded((B, T, H, W, C), 109), dtype)
+    leaves = hs + [fc1w, fc1b, fc2w, fc2b, x]
+    wg = torch.autograd.grad(want, leaves, go)
+    dev = [t.detach().cuda().to(dtype if t.dim() == 5 else torch.float32).requires_grad_(True) for t in leaves]
+    yd = FH.reweight_mix(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6])
+    got = FH.tanh_gate(dev[7], yd)
+    gg = torch.autograd.grad(got, dev, go.cuda().to(dtype))
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    for i, (g1, g2) in enumerate(zip(gg, wg)):
+        assert float((g1.float().cpu() - g2).abs().max()) <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(g2.abs().max())), i

@@ -1,0 +1,177 @@
+// HBM-bound kernels of the TAB token mixer (models/function.py:542-558 channel attention, :791-802 branch
+// re-weighting and tanh gate): one grouped row reduction and one coefficient-broadcast elementwise kernel.
+// Tensors are (G, R, C) channels-last views: G groups (frames for the channel attention, clips for the re-weighting),
+// R rows (pixels) per group, C channels.  Per-(group, channel) coefficients and all reductions are fp32.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct V16 {
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+
+// ------------------------------------------------------------------------------------------------ reduction
+// mode 0: out[g,c] += scale * sum_r (a [+ b + c3])[g,r,c]      mode 1: out[g,c] += scale * sum_r a*b
+// Threads run along channel PAIRS (4-byte loads for bf16, 8-byte for fp32), 256/tpr rows per block iteration; the
+// row-parallel partials are combined in LDS and added to the zero-initialised output with one float atomic per channel
+// and block.
+template <typename T>
+__global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c3,
+                                                           float* __restrict__ out, int G, long long R, int C, int mode, float scale,
+                                                           int chunks) {
+  __shared__ float red[2 * 256];
+  const int g = blockIdx.x / chunks, ck = blockIdx.x - g * chunks;
+  const int tpr = C >> 1;           // threads per row
+  const int rpb = 256 / tpr;        // rows per block iteration
+  const int roff = threadIdx.x / tpr, cp = threadIdx.x - roff * tpr;
+  const long long r0 = R * ck / chunks, r1 = R * (ck + 1) / chunks;
+  float s0 = 0.f, s1 = 0.f;
+  if (roff < rpb) {
+    const long long base = (long long)g * R * C + 2 * cp;
+    for (long long r = r0 + roff; r < r1; r += rpb) {
+      const long long o = base + r * C;
+      float x0 = to_f32(a[o]), x1 = to_f32(a[o + 1]);
+      if (mode == 0) {
+        if (b) { x0 += to_f32(b[o]); x1 += to_f32(b[o + 1]); }
+        if (c3) { x0 += to_f32(c3[o]); x1 += to_f32(c3[o + 1]); }
+      } else {
+        x0 *= to_f32(b[o]);
+        x1 *= to_f32(b[o + 1]);
+      }
+      s0 += x0;
+      s1 += x1;
+    }
+  }
+  red[2 * threadIdx.x] = s0;
+  red[2 * threadIdx.x + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < tpr) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < rpb; ++k) {
+      t0 += red[2 * (k * tpr + threadIdx.x)];
+      t1 += red[2 * (k * tpr + threadIdx.x) + 1];
+    }
+    atomicAdd(out + (long long)g * C + 2 * threadIdx.x, t0 * scale);
+    atomicAdd(out + (long long)g * C + 2 * threadIdx.x + 1, t1 * scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5 };
+
+template <typename T>
+__global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict__ p0, const T* __restrict__ p1, const T* __restrict__ p2,
+                                                     const float* __restrict__ coef, const float* __restrict__ add, float s,
+                                                     T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2, long long rows,
+                                                     long long R, int C) {
+  constexpr int VN = V16<T>::N;
+  const int nvec = C / VN;
+  const long long total = rows * nvec;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / nvec;
+    const int v = (int)(i - row * nvec);
+    const long long g = row / R;
+    const long long off = row * C + v * VN;
+    const long long gc = g * C + v * VN;
+    V16<T> a = *reinterpret_cast<const V16<T>*>(p0 + off);
+    V16<T> r0, r1, r2;
+    if (op == OP_CA_FWD) {  // (r * g + x) * s
+      const V16<T> x = *reinterpret_cast<const V16<T>*>(p1 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) r0.v[e] = from_f32<T>((to_f32(a.v[e]) * coef[gc + e] + to_f32(x.v[e])) * s);
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else if (op == OP_CA_BWD) {  // d_r = dy * s * g + add ; d_x = dy * s
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float d = to_f32(a.v[e]) * s;
+        r0.v[e] = from_f32<T>(d * coef[gc + e] + add[gc + e]);
+        r1.v[e] = from_f32<T>(d);
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+      *reinterpret_cast<V16<T>*>(o1 + off) = r1;
+    } else if (op == OP_MIX_FWD) {  // h*a0 + w*a1 + c*a2, coef (G, C, 3)
+      const V16<T> w = *reinterpret_cast<const V16<T>*>(p1 + off);
+      const V16<T> c = *reinterpret_cast<const V16<T>*>(p2 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float* k = coef + (gc + e) * 3;
+        r0.v[e] = from_f32<T>(to_f32(a.v[e]) * k[0] + to_f32(w.v[e]) * k[1] + to_f32(c.v[e]) * k[2]);
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else if (op == OP_MIX_BWD) {  // d_k = dy * a_k + add
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float* k = coef + (gc + e) * 3;
+        const float d = to_f32(a.v[e]), ad = add[gc + e];
+        r0.v[e] = from_f32<T>(d * k[0] + ad);
+        r1.v[e] = from_f32<T>(d * k[1] + ad);
+        r2.v[e] = from_f32<T>(d * k[2] + ad);
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+      *reinterpret_cast<V16<T>*>(o1 + off) = r1;
+      *reinterpret_cast<V16<T>*>(o2 + off) = r2;
+    } else if (op == OP_GATE_FWD) {  // (x + y) * tanh(y): p0 = x, p1 = y
+      const V16<T> y = *reinterpret_cast<const V16<T>*>(p1 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float yv = to_f32(y.v[e]);
+        r0.v[e] = from_f32<T>((to_f32(a.v[e]) + yv) * tanhf(yv));
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else {  // OP_GATE_BWD: p0 = dy, p1 = x, p2 = y -> dx = dy*t ; dy_ = dy*(t + (x+y)*(1-t^2))
+      const V16<T> x = *reinterpret_cast<const V16<T>*>(p1 + off);
+      const V16<T> y = *reinterpret_cast<const V16<T>*>(p2 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float d = to_f32(a.v[e]), xv = to_f32(x.v[e]), yv = to_f32(y.v[e]);
+        const float t = tanhf(yv);
+        r0.v[e] = from_f32<T>(d * t);
+        r1.v[e] = from_f32<T>(d * (t + (xv + yv) * (1.f - t * t)));
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+      *reinterpret_cast<V16<T>*>(o1 + off) = r1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode,
+                                float scale, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "group_reduce: bad dtype");
+  VMG_CHECK(a && out && G > 0 && R > 0 && C > 0 && (C & 1) == 0 && C <= 512, "group_reduce: bad arguments (C even, <= 512)");
+  VMG_CHECK(mode == 0 || (mode == 1 && b), "group_reduce: mode 1 needs b");
+  int chunks = (int)(1024 / G);
+  if (chunks < 1) chunks = 1;
+  if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(group_reduce_kernel<bf16>, dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out, G,
+                       (long long)R, C, mode, scale, chunks);
+  else
+    hipLaunchKernelGGL(group_reduce_kernel<float>, dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3, out,
+                       G, (long long)R, C, mode, scale, chunks);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add,
+                                   float s, void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "tab_elementwise: bad dtype");
+  VMG_CHECK(op >= 0 && op <= 5 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(C % vn == 0, "tab_elementwise: C must be a multiple of %d", vn);
+  const long long total = rows * (C / vn);
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(tab_ew_kernel<bf16>, dim3(blocks), dim3(256), 0, st, op, (const bf16*)p0, (const bf16*)p1, (const bf16*)p2, coef, add, s,
+                       (bf16*)o0, (bf16*)o1, (bf16*)o2, (long long)rows, (long long)R, C);
+  else
+    hipLaunchKernelGGL(tab_ew_kernel<float>, dim3(blocks), dim3(256), 0, st, op, (const float*)p0, (const float*)p1, (const float*)p2, coef, add,
+                       s, (float*)o0, (float*)o1, (float*)o2, (long long)rows, (long long)R, C);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}

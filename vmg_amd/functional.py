@@ -103,9 +103,9 @@ class _DeferredWgrad:
     def note_use(self, weight):
         self.uses[id(weight)] = self.uses.get(id(weight), 0) + 1
 
-    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W):
+    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0):
         ent = self.pending.setdefault(id(weight), [weight, bias, []])
-        ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W))
+        ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale)))
         left = self.uses.get(id(weight), 1) - 1
         if left <= 0:
             self.uses.pop(id(weight), None)
@@ -125,13 +125,13 @@ class _DeferredWgrad:
         db = bias.grad if (bias is not None and bias.requires_grad) else None
         groups = {}
         for e in entries:
-            sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]))
+            sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]), e[7])
             groups.setdefault(sig, []).append(e)
-        for (src_ch, ks, N, H, W, _, _), es in groups.items():
+        for (src_ch, ks, N, H, W, _, _, scale), es in groups.items():
             off = 0
             for i, c in enumerate(src_ch):
                 xs = [e[0][i][..., :c] if e[0][i].shape[-1] != c else e[0][i] for e in es]
-                K.conv_wgrad_batched(xs, [e[2] for e in es], weight.grad, db if i == 0 else None, ks, N, H, W, i0=off)
+                K.conv_wgrad_batched(xs, [e[2] for e in es], weight.grad, db if i == 0 else None, ks, N, H, W, scale=scale, i0=off)
                 off += c
         for cb in self.callbacks:
             cb(weight)
@@ -240,6 +240,90 @@ def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     return _Conv2d.apply(weight, bias, res, cfg, *srcs)
 
 
+class _ResidualChain(torch.autograd.Function):
+    """ResidualBlocksWithInputConv (models/trajectory.py:16-52, 165-221) as ONE autograd node:
+        y0 = lrelu_0.1(conv0(cat(srcs)));  y_{k+1} = y_k + r * conv2_k(relu(conv1_k(y_k)))
+    Forward is the same fused-epilogue conv launches as the generic path; the point is the BACKWARD, which runs the
+    data-gradient chain with everything fused into conv epilogues -- relu mask (actgrad), r scaling (alpha) and the
+    skip-path gradient (res) -- so there are no separate activation-backward or gradient-add kernels, and which only
+    records (input, output-gradient) pairs for the deferred batched weight gradient."""
+
+    @staticmethod
+    def forward(ctx, r_scaling, nsrc, *args):
+        srcs = list(args[:nsrc])
+        params = args[nsrc:]  # w0, b0, then (w1, b1, w2, b2) per block
+        nblk = (len(params) - 2) // 4
+        N, H, W = srcs[0].shape[0], srcs[0].shape[1], srcs[0].shape[2]
+        dt = srcs[0].dtype
+        M = N * H * W
+        src_ch = [t.shape[-1] for t in srcs]
+        w0, b0 = params[0], params[1]
+        C = w0.shape[0]
+        tiles, mt, deep = choose_tiling(M, C, 3, dt)
+        y, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=tiles), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=mt, deep=deep)
+        saved = [y]
+        for k in range(nblk):
+            w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
+            t, _ = K.conv_forward([y], packed(w1, dt, "fwd", [C], tiles=tiles), b1, N, H, W, act=hip.ACT_RELU, mt=mt, deep=deep)
+            y, _ = K.conv_forward([t], packed(w2, dt, "fwd", [C], tiles=tiles), b2, N, H, W, alpha=r_scaling, res=y, mt=mt, deep=deep)
+            saved += [t, y]
+        ctx.meta = (r_scaling, nsrc, nblk, N, H, W, src_ch, C)
+        ctx.defer = any(ctx.needs_input_grad[2 + nsrc:])
+        if ctx.defer:
+            for p in params[0::2]:
+                DEFERRED.note_use(p)
+        ctx.params = params
+        ctx.save_for_backward(*srcs, *saved[:-1])  # the final output is not needed
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        r, nsrc, nblk, N, H, W, src_ch, C = ctx.meta
+        params = ctx.params
+        srcs = list(ctx.saved_tensors[:nsrc])
+        saved = list(ctx.saved_tensors[nsrc:])  # y0, t0, y1, t1, ..., y_{nblk-1}, t_{nblk-1}   (y_nblk dropped)
+        g = g.contiguous()
+        dt = g.dtype
+        M = N * H * W
+        tiles, mt, deep = choose_tiling(M, C, 3, dt)
+        for k in range(nblk - 1, -1, -1):
+            w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
+            yk, tk = saved[2 * k], saved[2 * k + 1]
+            # d t_k = r * dgrad2(g) masked by relu'(t_k)
+            dt_k, _ = K.conv_forward([g], packed(w2, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, alpha=r, aux=tk, actgrad=1, mt=mt, deep=deep)
+            if ctx.defer:
+                DEFERRED.add(w2, b2, [tk], [C], g, 3, N, H, W, scale=r)
+                DEFERRED.add(w1, b1, [yk], [C], dt_k, 3, N, H, W)
+            # d y_k = g + dgrad1(d t_k)
+            g, _ = K.conv_forward([dt_k], packed(w1, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, res=g, mt=mt, deep=deep)
+        w0, b0 = params[0], params[1]
+        dpre0 = K.act_backward(g, saved[0], hip.ACT_LRELU, 0.1, 1.0)
+        d_srcs = []
+        off = 0
+        for i, c in enumerate(src_ch):
+            if ctx.needs_input_grad[2 + i]:
+                t_, m_, d_ = choose_tiling(M, c, 3, dt)
+                dx, _ = K.conv_forward([dpre0], packed(w0, dt, "dgrad", None, off, c, tiles=t_), None, N, H, W, mt=m_, deep=d_)
+                d_srcs.append(dx)
+            else:
+                d_srcs.append(None)
+            off += c
+        if ctx.defer:
+            DEFERRED.add(w0, b0, srcs, src_ch, dpre0, 3, N, H, W)
+        return (None, None, *d_srcs, *([None] * len(params)))
+
+
+def residual_chain(srcs: Sequence[torch.Tensor], conv0, blocks, r_scaling: float) -> torch.Tensor:
+    """srcs: channels-last (n,h,w,c_s) tensors (virtual concat); conv0 and blocks[k].conv1/.conv2 are nn.Conv2d holders."""
+    params = [conv0.weight, conv0.bias]
+    for b in blocks:
+        params += [b.conv1.weight, b.conv1.bias, b.conv2.weight, b.conv2.bias]
+    ok = all(isinstance(p, torch.nn.Parameter) for p in params) and all(t.is_contiguous() and t.shape[-1] % 8 == 0 for t in srcs)
+    if not ok:
+        raise HipError("residual_chain needs contiguous sources with multiples of 8 channels and nn.Parameter weights")
+    return _ResidualChain.apply(float(r_scaling), len(srcs), *srcs, *params)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = hip.ACT_NONE, alpha: float = 1.0,
            res: Optional[torch.Tensor] = None, slope: float = 0.0) -> torch.Tensor:
     """y[..., O] = act(x[..., I] @ W^T + b) * alpha (+ res): the KS = 1 convolution on (M, C) rows."""
@@ -308,26 +392,100 @@ def morph_untokens(t: torch.Tensor, axis: str, chunk: int, Cp: int, H: int, W: i
     return u.reshape(B, T, H, Wp, Cp)[..., 0:W, :C].contiguous()
 
 
+class _ChannelAttention(torch.autograd.Function):
+    """(r * sigmoid(W2 relu(W1 GAP(r) + b1) + b2) + x) * s on (N,H,W,C): CALayer + RCAB residual (models/function.py:555-558,
+    581).  The two full-tensor passes (GAP reduction, scale+residual) are HIP kernels; the (N,C)-sized squeeze-excite MLP
+    and its backward are a handful of tiny fp32 ops."""
+
+    @staticmethod
+    def forward(ctx, r, x, w1, b1, w2, b2, s):
+        r, x = r.contiguous(), x.contiguous()
+        N, C = r.shape[0], r.shape[-1]
+        R = r.numel() // (N * C)
+        w1m, w2m = w1.flatten(1), w2.flatten(1)
+        m = K.group_reduce(r, N, scale=1.0 / R)
+        z1 = torch.relu(torch.addmm(b1, m, w1m.t()))
+        g = torch.sigmoid(torch.addmm(b2, z1, w2m.t()))
+        out = K.tab_elementwise(K.OP_CA_FWD, r, x, coef=g, s=s, G=N)
+        ctx.s, ctx.R = s, R
+        ctx.save_for_backward(r, g, m, z1, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        r, g, m, z1, w1, w2 = ctx.saved_tensors
+        s, R = ctx.s, ctx.R
+        dy = dy.contiguous()
+        N = r.shape[0]
+        w1m, w2m = w1.flatten(1), w2.flatten(1)
+        dg = K.group_reduce(dy, N, b=r, mode=1, scale=s)          # d out / d g summed over pixels
+        dz2 = dg * g * (1 - g)
+        dz1 = (dz2 @ w2m) * (z1 > 0)
+        dm = dz1 @ w1m                                             # gradient of the GAP output
+        d_r, d_x = K.tab_elementwise(K.OP_CA_BWD, dy, coef=g, add=(dm / R).contiguous(), s=s, G=N, nout=2)
+        return (d_r, d_x, (dz1.t() @ m).reshape(w1.shape), dz1.sum(0), (dz2.t() @ z1).reshape(w2.shape), dz2.sum(0), None)
+
+
 def channel_attention_residual(r, x, w1, b1, w2, b2, out_scale: float):
-    """(r * sigmoid(W2 relu(W1 GAP(r) + b1) + b2) + x) * out_scale on (N,H,W,C) (models/function.py:555-558, 581)."""
-    g = r.float().mean((1, 2))
-    g = F.relu(F.linear(g, w1.flatten(1), b1))
-    g = torch.sigmoid(F.linear(g, w2.flatten(1), b2)).to(r.dtype)
-    return (r * g[:, None, None, :] + x) * out_scale
+    return _ChannelAttention.apply(r, x, w1, b1, w2, b2, float(out_scale))
+
+
+class _ReweightMix(torch.autograd.Function):
+    """Softmax re-weighting of the three mixer branches (models/function.py:791-793):
+    a = softmax_3(Mlp(mean_{T,H,W}(h + w + c)));  y = h*a0 + w*a1 + c*a2."""
+
+    @staticmethod
+    def forward(ctx, h, w, c, fc1w, fc1b, fc2w, fc2b):
+        h, w, c = h.contiguous(), w.contiguous(), c.contiguous()
+        B, C = h.shape[0], h.shape[-1]
+        R = h.numel() // (B * C)
+        m = K.group_reduce(h, B, b=w, c3=c, scale=1.0 / R)
+        pre = torch.addmm(fc1b, m, fc1w.t())
+        u = torch.nn.functional.gelu(pre)
+        a = torch.addmm(fc2b, u, fc2w.t()).reshape(B, C, 3).softmax(-1).contiguous()
+        y = K.tab_elementwise(K.OP_MIX_FWD, h, w, c, coef=a, G=B)
+        ctx.R = R
+        ctx.save_for_backward(h, w, c, a, m, pre, u, fc1w, fc2w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, c, a, m, pre, u, fc1w, fc2w = ctx.saved_tensors
+        R = ctx.R
+        dy = dy.contiguous()
+        B, C = h.shape[0], h.shape[-1]
+        da = torch.stack([K.group_reduce(dy, B, b=t, mode=1) for t in (h, w, c)], -1)  # (B,C,3)
+        dv = (a * (da - (a * da).sum(-1, keepdim=True))).reshape(B, 3 * C)             # softmax backward
+        du = dv @ fc2w
+        x = pre
+        dpre = du * (0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327)
+        dm = dpre @ fc1w
+        dh, dw, dc = K.tab_elementwise(K.OP_MIX_BWD, dy, coef=a, add=(dm / R).contiguous(), G=B, nout=3)
+        return dh, dw, dc, dpre.t() @ m, dpre.sum(0), dv.t() @ u, dv.sum(0)
 
 
 def reweight_mix(h, w, c, fc1w, fc1b, fc2w, fc2b):
-    """softmax re-weighting of the three branches (models/function.py:791-793): a = Mlp(mean_{T,H,W}(h+w+c))."""
-    B, C = h.shape[0], h.shape[-1]
-    a = (h.float() + w.float() + c.float()).mean((1, 2, 3))
-    a = F.linear(F.gelu(F.linear(a, fc1w, fc1b)), fc2w, fc2b).reshape(B, C, 3).softmax(-1).to(h.dtype)
-    a = a[:, None, None, None]
-    return h * a[..., 0] + w * a[..., 1] + c * a[..., 2]
+    return _ReweightMix.apply(h, w, c, fc1w, fc1b, fc2w, fc2b)
+
+
+class _TanhGate(torch.autograd.Function):
+    """(x + y) * tanh(y) (models/function.py:801-802)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        ctx.save_for_backward(x, y)
+        return K.tab_elementwise(K.OP_GATE_FWD, x, y)
+
+    @staticmethod
+    def backward(ctx, d):
+        x, y = ctx.saved_tensors
+        dx, dy = K.tab_elementwise(K.OP_GATE_BWD, d.contiguous(), x, y, nout=2)
+        return dx, dy
 
 
 def tanh_gate(x, y):
-    """(x + y) * tanh(y) (models/function.py:801-802)."""
-    return (x + y) * torch.tanh(y)
+    return _TanhGate.apply(x, y)
 
 
 def identity_grid(n: int, h: int, w: int, device) -> torch.Tensor:

@@ -65,6 +65,9 @@ SIGNATURES = {
     "vmg_conv_wgrad_ws_bytes": (c_int64, []),
     "vmg_conv_wgrad_batched_ws": (c_int, [c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int64, c_int,
                                           c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    "vmg_group_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "vmg_tab_elementwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_int, c_void_p]),
     "vmg_prof_begin": (c_int, [c_int, c_int, c_int]),
     "vmg_prof_end": (c_int, [POINTER(c_int64), POINTER(c_int), POINTER(ctypes.c_double)]),
     "vmg_conv_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

@@ -359,3 +359,39 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
                                      decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
                                      drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")
     return dq, dk, dv, drpe
+
+
+OP_CA_FWD, OP_CA_BWD, OP_MIX_FWD, OP_MIX_BWD, OP_GATE_FWD, OP_GATE_BWD = range(6)
+
+
+def group_reduce(a: torch.Tensor, G: int, b: Optional[torch.Tensor] = None, c3: Optional[torch.Tensor] = None, mode: int = 0,
+                 scale: float = 1.0) -> torch.Tensor:
+    """a (and b, c3): contiguous (G*R, C)-shaped data; returns fp32 (G, C): scale * sum_r of (a+b+c3) or of a*b."""
+    hip.require_cuda(a, b, c3)
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if rows % G or not a.is_contiguous() or any(t is not None and (t.shape != a.shape or t.dtype != a.dtype or not t.is_contiguous()) for t in (b, c3)):
+        raise HipError("group_reduce: contiguous tensors of one shape / dtype covering G groups expected")
+    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    hip.check(hip.lib().vmg_group_reduce(hip.dtype_code(a.dtype), a.data_ptr(), b.data_ptr() if b is not None else None,
+                                         c3.data_ptr() if c3 is not None else None, out.data_ptr(), G, rows // G, C, mode, scale,
+                                         hip.stream_ptr()), "vmg_group_reduce")
+    return out
+
+
+def tab_elementwise(op: int, p0, p1=None, p2=None, coef=None, add=None, s: float = 1.0, G: int = 1, nout: int = 1):
+    hip.require_cuda(p0, p1, p2, coef, add)
+    C = p0.shape[-1]
+    rows = p0.numel() // C
+    for t in (p0, p1, p2):
+        if t is not None and (not t.is_contiguous() or t.shape != p0.shape or t.dtype != p0.dtype):
+            raise HipError("tab_elementwise: contiguous operands of one shape / dtype expected")
+    for t in (coef, add):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise HipError("tab_elementwise: coefficients must be contiguous fp32")
+    outs = [torch.empty_like(p0) for _ in range(nout)]
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    o = outs + [None] * (3 - nout)
+    hip.check(hip.lib().vmg_tab_elementwise(hip.dtype_code(p0.dtype), op, ptr(p0), ptr(p1), ptr(p2), ptr(coef), ptr(add), s, ptr(o[0]),
+                                            ptr(o[1]), ptr(o[2]), rows, rows // G, C, hip.stream_ptr()), "vmg_tab_elementwise")
+    return outs[0] if nout == 1 else outs

@@ -304,12 +304,9 @@ class ResidualBlocksWithInputConv(nn.Module):
                                   nn.Sequential(*[ResidualBlockNoBN0(out_channels, r_scaling) for _ in range(num_blocks)]))
 
     def forward(self, srcs: Sequence[torch.Tensor]):
-        N, H, W, _ = srcs[0].shape
-        x = conv(self.main[0], srcs, N, H, W, act=ACT_LRELU, slope=0.1)
-        for blk in self.main[2]:
-            y = conv(blk.conv1, [x], N, H, W, act=ACT_RELU)
-            x = conv(blk.conv2, [y], N, H, W, alpha=blk.res_scale, res=x)
-        return x
+        blocks = list(self.main[2])
+        r = blocks[0].res_scale if blocks else 1.0
+        return FH.residual_chain([t.contiguous() for t in srcs], self.main[0], blocks, r)
 
 
 class LTAM_multi_head(nn.Module):
