@@ -199,6 +199,9 @@ int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* 
  * ---------------------------------------------------------------------------------------------- */
 int vmg_prof_begin(int klass, int stride, int max_samples);
 int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms);
+/* event-pair interval (microseconds) around an empty one-wave kernel: the dispatch + event latency that the intervals
+ * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
+double vmg_prof_null_interval_us(int reps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,8 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["LDS_Block_Size"], r["VGPR_Count"],
-                         r["Accum_VGPR_Count"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Grid_Size_X"] + "x" + r["Grid_Size_Y"],
+                         r["VGPR_Count"], r["Accum_VGPR_Count"]))
     rows.sort()
     t_end = rows[-1][1]
     win = [r for r in rows if r[0] >= t_end - int(window_ms * 1e6)]
@@ -30,9 +30,9 @@ def main():
     tot = sum(v[1] for v in agg.values())
     print(f"# window {window_ms} ms before the last kernel end: {len(win)} dispatches, span {(win[-1][1] - win[0][0]) / 1e6:.2f} ms, "
           f"GPU busy {tot / 1e6:.2f} ms", file=out)
-    print("# pct  calls  avg_us  min_us  max_us  LDS  VGPR  AGPR  kernel", file=out)
+    print("# pct  calls  avg_us  min_us  max_us  grid(threads)  VGPR  AGPR  kernel   [one line per (kernel, grid)]", file=out)
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{100 * v[1] / tot:6.2f} {v[0]:6d} {v[1] / v[0] / 1e3:9.1f} {v[2] / 1e3:8.1f} {v[3] / 1e3:8.1f} {k[1]:>6} {k[2]:>4} {k[3]:>4}  {k[0]}", file=out)
+        print(f"{100 * v[1] / tot:6.2f} {v[0]:6d} {v[1] / v[0] / 1e3:9.1f} {v[2] / 1e3:8.1f} {v[3] / 1e3:8.1f} {k[1]:>10} {k[2]:>4} {k[3]:>4}  {k[0]}", file=out)
 
 
 if __name__ == "__main__":

@@ -65,3 +65,30 @@ extern "C" int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_
   g_prof.klass = 0; g_prof.used = 0;
   return 0;
 }
+
+// Event-pair interval of an empty one-wave kernel on `stream`: what the HIP events of vmg_prof_begin add on
+// top of a kernel's own duration (dispatch + event latency).  bench.py subtracts it so that its live number agrees
+// with rocprofv3's kernel timestamps.
+__global__ void vmg_null_kernel(int* p) {
+  if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 0;
+}
+
+extern "C" double vmg_prof_null_interval_us(int reps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  double tot = 0.0;
+  int n = 0;
+  for (int i = 0; i < reps + 3; ++i) {
+    hipLaunchKernelGGL(vmg_null_kernel, dim3(512, 1), dim3(256), 0, st, (int*)nullptr);  // a predecessor, as in the real chain
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(vmg_null_kernel, dim3(1, 1), dim3(64), 0, st, (int*)nullptr);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (i >= 3 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { tot += ms; ++n; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return n ? tot / n * 1000.0 : -1.0;
+}
