@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, T, H, W = 4, 7, 64, 64
 FWD_GFLOP_PER_FRAME = 292.8  # Conv+Linear, measured on the reference (SURVEY section 6 / BASELINE.md section 2)
 K1_FLOPS_PER_PIXEL = 2.0 * 144 * 144 * 9  # the dominant kernel: conv3x3 144->144
+K1_PIXELS = 2 * B_PER_GPU * H * W          # ... over one frame of every clip for BOTH direction sweeps (run in lockstep)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -123,6 +124,7 @@ def main():
     null_us = 0.0
     if not args.no_prof:
         null_us = float(lib.vmg_prof_null_interval_us(50, hip.stream_ptr()))  # event-pair interval of an empty kernel
+        hip.check(lib.vmg_prof_select_pixels(K1_PIXELS), "vmg_prof_select_pixels")
         hip.check(lib.vmg_prof_begin(1, 16, 4096), "vmg_prof_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -144,9 +146,9 @@ def main():
             # rocprofv3's kernel timestamps exclude.  null_kernel_interval_us (the same event pair around an empty one-wave
             # kernel) bounds that latency: rocprof's average lies between raw - null and raw.
             avg_s = raw_us * 1e-6
-            flops = K1_FLOPS_PER_PIXEL * B_PER_GPU * H * W  # algorithmic FLOPs of one launch (M = 16384 pixels)
+            flops = K1_FLOPS_PER_PIXEL * K1_PIXELS  # algorithmic FLOPs of one launch
             ach = flops / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,KS=3,MT=1,NTB=5> (conv3x3 144->144 on 16384 px, fwd+dgrad of the recurrent chains)",
+            roofline = {"bound": "mfma", "kernel": "conv3x3 144->144 bf16 on %d px (fwd + dgrad of the recurrent chains; both direction sweeps in one launch)" % K1_PIXELS,
                         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2), "event_interval_us": round(raw_us, 2),
                         "null_kernel_interval_us": round(null_us, 2), "launches_per_step": seen.value // max(1, args.steps),

@@ -95,7 +95,8 @@ typedef struct vmg_conv_desc {
   int actgrad;
   int pixel_shuffle;
   int mt;   /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
-  int deep; /* 1 = 3-slot counted-wait weight ring (one workgroup per CU; latency-critical small grids), 0 = 2-slot */
+  int deep; /* kernel variant: 0 = 2-slot weight ring, 1 = 3-slot counted-wait ring, 2 = K split over the 4 waves with
+              * weights read global->register (bf16, cout_tiles <= 5, mt 1) */
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
@@ -199,6 +200,8 @@ int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* 
  * ---------------------------------------------------------------------------------------------- */
 int vmg_prof_begin(int klass, int stride, int max_samples);
 int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms);
+/* restrict the timed launches to those over exactly `pixels` pixels (N*H*W); 0 = any size */
+int vmg_prof_select_pixels(int64_t pixels);
 /* event-pair interval (microseconds) around an empty one-wave kernel: the dispatch + event latency that the intervals
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);

@@ -227,3 +227,59 @@ def test_conv_wgrad_batched_large_tile(shape):
     scale = max(1.0, float(gw.abs().max()))
     assert float((outs[0][0] - (init_w + 0.5 * gw)).abs().max()) <= 2e-3 * scale
     assert float((outs[0][1] - (init_b + 0.5 * gb)).abs().max()) <= 2e-3 * max(1.0, float(gb.abs().max()))
+
+
+@pytest.mark.parametrize("tiles", [5, 4])
+@pytest.mark.parametrize("shape", [(2, 24, 20, 144, 144), (1, 64, 64, 144, 144), (3, 9, 17, 64, 64), (1, 16, 16, 144, 288), (1, 8, 8, 112, 224),
+                                   (2, 16, 32, 64, 3), (1, 10, 10, 8, 16)])
+def test_conv3x3_ksplit_variant(shape, tiles):
+    """The K-split kernel (deep=2: waves split the K loop, partial tiles reduced through LDS) against the oracle, with
+    every fused epilogue: bias + ReLU, activation-gradient mask + residual, scale."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, Ci, Co = shape
+    x = R.seeded((N, H, W, Ci), 41)
+    w = R.seeded((Co, Ci, 3, 3), 42, (Ci * 9) ** -0.5)
+    b = R.seeded((Co,), 43, 0.1)
+    conv = O.conv_nhwc(_q(x, dtype), _q(w, dtype), b, 1)
+    pw = K.pack_conv_weight(w.cuda(), dtype, cout_tiles=tiles)
+    got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_RELU, deep=2)
+    _cmp(got, F.relu(conv), dtype, f"k-split conv3x3 {shape}")
+    aux, res = R.seeded((N, H, W, Co), 44), R.seeded((N, H, W, Co), 45)
+    want = _q(res, dtype) + 0.5 * conv * (_q(aux, dtype) > 0).float()
+    got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, alpha=0.5, res=res.cuda().to(dtype), aux=aux.cuda().to(dtype),
+                            actgrad=1, deep=2)
+    _cmp(got, want, dtype, f"k-split conv3x3 mask+residual {shape}")
+
+
+def test_conv_ksplit_concat_linear_and_repeatability():
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, C = 2, 16, 32, 144
+    x1, x2 = R.seeded((N, H, W, C), 46), R.seeded((N, H, W, C), 47)
+    w = R.seeded((C, 2 * C, 3, 3), 48, (2 * C * 9) ** -0.5)
+    b = R.seeded((C,), 49, 0.1)
+    want = F.leaky_relu(O.conv_nhwc(torch.cat([_q(x1, dtype), _q(x2, dtype)], -1), _q(w, dtype), b, 1), 0.1)
+    pw = K.pack_conv_weight(w.cuda(), dtype, src_ch=[C, C], cout_tiles=5)
+    got, _ = K.conv_forward([x1.cuda().to(dtype), x2.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1, deep=2)
+    _cmp(got, want, dtype, "k-split concat conv")
+    # 1x1 (Linear) with GELU and the pre-activation output, ragged M
+    M, Ci, Co = 1000, 144, 288
+    x = R.seeded((M, Ci), 50)
+    wl = R.seeded((Co, Ci), 51, Ci ** -0.5)
+    bl = R.seeded((Co,), 52, 0.1)
+    pre = F.linear(_q(x, dtype), _q(wl, dtype), bl)
+    pwl = K.pack_conv_weight(wl.cuda(), dtype, cout_tiles=5)
+    got, got_pre = K.conv_forward([x.cuda().to(dtype)], pwl, bl.cuda(), 1, 1, M, act=hip.ACT_GELU, want_pre=True, deep=2)
+    _cmp(got_pre.reshape(M, Co), pre, dtype, "k-split linear pre")
+    _cmp(got.reshape(M, Co), F.gelu(pre), dtype, "k-split linear gelu")
+    # run-to-run identical under load (two workgroups per CU, LDS scratch aliased over the halo tile)
+    xb = R.seeded((8, 64, 64, C), 53).cuda().to(dtype)
+    w2 = R.seeded((C, C, 3, 3), 54, (C * 9) ** -0.5)
+    pw2 = K.pack_conv_weight(w2.cuda(), dtype, cout_tiles=5)
+    first = K.conv_forward([xb], pw2, None, 8, 64, 64, deep=2)[0].clone()
+    ref = K.conv_forward([xb], pw2, None, 8, 64, 64, deep=0)[0]
+    assert float((first.float() - ref.float()).abs().max()) <= 2e-2 * max(1.0, float(ref.float().abs().max()))
+    for _ in range(20):
+        again = K.conv_forward([xb], pw2, None, 8, 64, 64, deep=2)[0]
+        assert torch.equal(first, again)

@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 void vmg_set_error(const char* fmt, ...);
 
 // live timing hooks (runtime.hip); kernel classes: 1 = conv3x3 fwd/dgrad bf16 C<=160 -> C<=160, 2 = conv wgrad
-bool vmg_prof_before(int klass, hipStream_t st);
+bool vmg_prof_before(int klass, long long pixels, hipStream_t st);
 void vmg_prof_after(hipStream_t st);
 #define VMG_PROF_CONV3X3 1
 #define VMG_PROF_WGRAD 2

@@ -98,66 +98,16 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& w, const Frag<float>& x,
   return c;
 }
 
-template <typename T, int KS, int MT, int NTB, bool DEEP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
-  constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
+// ---- stage the halo tile of source s in LDS: (THH rows) x (TWH pixels) x ch channels (all 256 threads; no barriers
+// inside -- the caller brackets it)
+template <typename T, int KS, int MT>
+__device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, int n, int ty, int tx, long long m0, int tid) {
+  constexpr int ES = ElemTraits<T>::ES;
   constexpr int TH = 4 * MT;
   constexpr int TWH = (KS == 3) ? 18 : 16;
   constexpr int THH = (KS == 3) ? TH + 2 : TH;
-  constexpr int COB = NTB * 16;
-  constexpr int KSTG = kstg(KS), RING = DEEP ? 3 : 2;
-  constexpr int SS = stage_stride(KS, NTB, CB);  // stage image size in LDS and in the packed weights
-  constexpr int IPW = SS / 4096;                 // global_load_lds instructions per wave per stage
-  constexpr int KK = KS * KS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wbuf = smem + a.halo_bytes;
-  if (a.dbg & 16) return;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int px = lane & 15, g = lane >> 4;
-  const int cb = blockIdx.y;
-  // 16-channel tiles this block really has (the last block of a layer may be short: its MFMAs are skipped, wave-uniform)
-  const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
-  int n = 0, ty = 0, tx = 0;
-  long long m0 = 0;
-  if (KS == 3) {
-    int bid = blockIdx.x;
-    tx = bid % a.tiles_x;
-    int r = bid / a.tiles_x;
-    ty = r % a.tiles_y;
-    n = r / a.tiles_y;
-  } else {
-    m0 = (long long)blockIdx.x * (64 * MT);
-  }
-
-  f32x4 acc[NTB][MT];
-#pragma unroll
-  for (int ct = 0; ct < NTB; ++ct)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nstages = a.nstages;
-  const char* wsrc = a.wpack + (long long)cb * nstages * SS + (wave * 1024 + lane * 16);
-  auto issue_w = [&](int stage) {
-    if (a.dbg & 1) return;
-    const char* gsrc = wsrc + (long long)stage * SS;
-    char* dst = wbuf + (stage % RING) * SS + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + i * 4096), LDS_PTR(dst + i * 4096), 16, 0, 0);
-  };
-
-#pragma unroll
-  for (int i = 0; i < RING - 1; ++i)
-    if (i < nstages) issue_w(i);
-  int gst = 0;  // global stage index
-  for (int s = 0; s < a.nsrc; ++s) {
-    const int ch = a.src_ch[s], pixb = a.src_pixb[s];
-    const int CH = ch >> 3;  // 8-channel chunks of this source
-    __syncthreads();         // everyone is done reading the previous halo tile
-    const bool after_restage = s > 0;  // LDS-DMA of the halo is younger than the weight stages in flight: see the stage wait
-    {
-      // ---- stage the halo tile of this source: (THH rows) x (TWH pixels) x ch channels.
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ch = a.src_ch[s], pixb = a.src_pixb[s];
       const char* sp = a.src[s];
       const long long ps_b = a.src_ps[s] * ES;
       const int vpp = ch * ES / 16;  // 16-byte vectors per pixel
@@ -228,7 +178,217 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
             if (dsto[b] >= 0) *reinterpret_cast<uint4*>(halo + dsto[b]) = inb[b] ? val[b] : make_uint4(0, 0, 0, 0);
         }
       }
+}
+
+// 4 consecutive elements kept in their storage type (operands of the epilogue fetched before the main loop)
+template <typename T>
+struct Raw4;
+template <>
+struct Raw4<bf16> {
+  bf16x4 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x4*>(p); }
+  __device__ __forceinline__ void get(float o[4]) const { o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+};
+template <>
+struct Raw4<float> {
+  float4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void get(float o[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+
+// pixel of lane px in row `row` of the workgroup's tile
+template <int KS>
+__device__ __forceinline__ bool conv_row_pixel(const ConvK& a, int row, int TH, int n, int ty, int tx, long long m0, int px, long long& pix) {
+  if (KS == 3) {
+    const int y = ty * TH + row, x = tx * 16 + px;
+    pix = ((long long)n * a.H + y) * a.W + x;
+    return (y < a.H) && (x < a.W);
+  }
+  pix = m0 + row * 16 + px;
+  return pix < a.M;
+}
+__device__ __forceinline__ bool conv_epilogue_fast(const ConvK& a) {
+  const bool vec_ok = ((a.Cout & 3) == 0) && ((a.out_ps & 3) == 0) && (!a.res || (a.res_ps & 3) == 0) && (!a.aux || (a.aux_ps & 3) == 0);
+  return vec_ok && ((a.Cout & 15) == 0);
+}
+
+// ---- epilogue of one 16-pixel row (row `row` of the workgroup's tile): acc[ct] holds, per lane, output channels
+// cb*COB + ct*16 + 4g .. +3 of pixel px.  bias, activation, scale, activation-gradient mask, residual, PixelShuffle.
+// PRE: the residual / activation-gradient operands of the fast path were fetched earlier into pre_res / pre_aux, and
+// `lbias` (LDS) holds the block's COB bias values.
+template <typename T, int KS, int NTB, bool PRE = false>
+__device__ __forceinline__ void conv_epilogue_row(const ConvK& a, const f32x4 (&acc)[NTB], int row, int TH, int cb, int nt_real, int n, int ty,
+                                                  int tx, long long m0, int px, int g, const Raw4<T>* pre_res = nullptr,
+                                                  const Raw4<T>* pre_aux = nullptr, const float* lbias = nullptr) {
+  constexpr int COB = NTB * 16;
+  T* out = reinterpret_cast<T*>(a.out);
+  T* out_pre = reinterpret_cast<T*>(a.out_pre);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  const T* aux = reinterpret_cast<const T*>(a.aux);
+  const bool vec_ok = ((a.Cout & 3) == 0) && ((a.out_ps & 3) == 0) && (!res || (a.res_ps & 3) == 0) &&
+                      (!aux || (a.aux_ps & 3) == 0);
+  const bool fast = vec_ok && ((a.Cout & 15) == 0);  // every real tile of this block is complete: straight-line path
+  // ReLU / LeakyReLU / none as one select: t > 0 ? t : t * neg
+  const float neg = a.act == VMG_ACT_RELU ? 0.f : (a.act == VMG_ACT_LRELU ? a.slope : 1.f);
+  {
+    long long pix;
+    bool valid;
+    int y = 0, x = 0;
+    if (KS == 3) {
+      y = ty * TH + row;
+      x = tx * 16 + px;
+      valid = (y < a.H) && (x < a.W);
+      pix = ((long long)n * a.H + y) * a.W + x;
+    } else {
+      pix = m0 + row * 16 + px;
+      valid = pix < a.M;
+      if (a.ps) {
+        x = (int)(pix % a.W);
+        const long long t = pix / a.W;
+        y = (int)(t % a.H);
+        n = (int)(t / a.H);
+      }
     }
+    if (!valid || (a.dbg & 8)) return;
+    if (fast) {
+#pragma unroll
+      for (int ct = 0; ct < NTB; ++ct) {
+        if (ct < nt_real) {
+          const int co0 = cb * COB + ct * 16 + g * 4;
+          float v[4] = {acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]};
+          if (a.bias) {
+            const float4 bv = PRE ? *reinterpret_cast<const float4*>(lbias + ct * 16 + g * 4) : *reinterpret_cast<const float4*>(a.bias + co0);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (out_pre) store4(out_pre + pix * a.out_ps + co0, v);
+          if (a.act == VMG_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]) * a.alpha;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * neg) * a.alpha;
+          }
+          if (aux) {
+            float u[4];
+            if (PRE) pre_aux[ct].get(u);
+            else load4(aux + pix * a.aux_ps + co0, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = a.actgrad == 3 ? gelu_erf_grad(u[r]) : (u[r] > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+              v[r] *= d;
+            }
+          }
+          if (res) {
+            float u[4];
+            if (PRE) pre_res[ct].get(u);
+            else load4(res + pix * a.res_ps + co0, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += u[r];
+          }
+          if (a.ps) {
+            // torch PixelShuffle(2): channel co = c*4 + i*2 + j -> out[n, 2y+i, 2x+j, c]
+            const int c = co0 >> 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const long long op = ((long long)n * (2 * a.H) + (2 * y + (r >> 1))) * (2 * a.W) + (2 * x + (r & 1));
+              out[op * a.out_ps + c] = from_f32<T>(v[r]);
+            }
+          } else {
+            store4(out + pix * a.out_ps + co0, v);
+          }
+        }
+      }
+      return;
+    }
+    // general path (Cout not a multiple of 16, or unaligned strides): element-wise with bounds checks
+    for (int ct = 0; ct < nt_real; ++ct) {
+      const int co0 = cb * COB + ct * 16 + g * 4;
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + r;
+        if (co >= a.Cout) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < NTB; ++c2)  // static register index
+          if (c2 == ct) t = r == 0 ? acc[c2][0] : (r == 1 ? acc[c2][1] : (r == 2 ? acc[c2][2] : acc[c2][3]));
+        if (a.bias) t += a.bias[co];
+        if (out_pre) out_pre[pix * a.out_ps + co] = from_f32<T>(t);
+        if (a.act == VMG_ACT_GELU) t = gelu_erf(t) * a.alpha;
+        else t = (t > 0.f ? t : t * neg) * a.alpha;
+        if (aux) {
+          const float u = to_f32(aux[pix * a.aux_ps + co]);
+          t *= a.actgrad == 3 ? gelu_erf_grad(u) : (u > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+        }
+        if (res) t += to_f32(res[pix * a.res_ps + co]);
+        if (a.ps) {
+          const long long op = ((long long)n * (2 * a.H) + (2 * y + ((co & 3) >> 1))) * (2 * a.W) + (2 * x + (co & 1));
+          out[op * a.out_ps + (co >> 2)] = from_f32<T>(t);
+        } else {
+          out[pix * a.out_ps + co] = from_f32<T>(t);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int MT, int NTB, bool DEEP>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
+  constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
+  constexpr int TH = 4 * MT;
+  constexpr int TWH = (KS == 3) ? 18 : 16;
+  constexpr int THH = (KS == 3) ? TH + 2 : TH;
+  constexpr int COB = NTB * 16;
+  constexpr int KSTG = kstg(KS), RING = DEEP ? 3 : 2;
+  constexpr int SS = stage_stride(KS, NTB, CB);  // stage image size in LDS and in the packed weights
+  constexpr int IPW = SS / 4096;                 // global_load_lds instructions per wave per stage
+  constexpr int KK = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + a.halo_bytes;
+  if (a.dbg & 16) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  // 16-channel tiles this block really has (the last block of a layer may be short: its MFMAs are skipped, wave-uniform)
+  const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
+  int n = 0, ty = 0, tx = 0;
+  long long m0 = 0;
+  if (KS == 3) {
+    int bid = blockIdx.x;
+    tx = bid % a.tiles_x;
+    int r = bid / a.tiles_x;
+    ty = r % a.tiles_y;
+    n = r / a.tiles_y;
+  } else {
+    m0 = (long long)blockIdx.x * (64 * MT);
+  }
+
+  f32x4 acc[NTB][MT];
+#pragma unroll
+  for (int ct = 0; ct < NTB; ++ct)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nstages = a.nstages;
+  const char* wsrc = a.wpack + (long long)cb * nstages * SS + (wave * 1024 + lane * 16);
+  auto issue_w = [&](int stage) {
+    if (a.dbg & 1) return;
+    const char* gsrc = wsrc + (long long)stage * SS;
+    char* dst = wbuf + (stage % RING) * SS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + i * 4096), LDS_PTR(dst + i * 4096), 16, 0, 0);
+  };
+
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i)
+    if (i < nstages) issue_w(i);
+  int gst = 0;  // global stage index
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int ch = a.src_ch[s], pixb = a.src_pixb[s];
+    const int CH = ch >> 3;  // 8-channel chunks of this source
+    __syncthreads();         // everyone is done reading the previous halo tile
+    const bool after_restage = s > 0;  // LDS-DMA of the halo is younger than the weight stages in flight: see the stage wait
+    stage_halo<T, KS, MT>(a, s, halo, n, ty, tx, m0, tid);
     __syncthreads();
 
     // per-lane pixel base addresses in the halo tile
@@ -288,112 +448,181 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---------------------------------------------------------------------------------------- epilogue
-  T* out = reinterpret_cast<T*>(a.out);
-  T* out_pre = reinterpret_cast<T*>(a.out_pre);
-  const T* res = reinterpret_cast<const T*>(a.res);
-  const T* aux = reinterpret_cast<const T*>(a.aux);
-  const bool vec_ok = ((a.Cout & 3) == 0) && ((a.out_ps & 3) == 0) && (!res || (a.res_ps & 3) == 0) &&
-                      (!aux || (a.aux_ps & 3) == 0);
-  const bool fast = vec_ok && ((a.Cout & 15) == 0);  // every real tile of this block is complete: straight-line path
-  // ReLU / LeakyReLU / none as one select: t > 0 ? t : t * neg
-  const float neg = a.act == VMG_ACT_RELU ? 0.f : (a.act == VMG_ACT_LRELU ? a.slope : 1.f);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    f32x4 r[NTB];
+#pragma unroll
+    for (int ct = 0; ct < NTB; ++ct) r[ct] = acc[ct][mt];
+    conv_epilogue_row<T, KS, NTB>(a, r, wave * MT + mt, TH, cb, nt_real, n, ty, tx, m0, px, g);
+  }
+}
+
+// ================================================================================================ K-split variant
+// Same decomposition of the OUTPUT (64 pixels x NTB*16 channels per workgroup, epilogue row w on wave w), but the four
+// waves split the K loop instead of the pixels: every wave accumulates the whole 64 x COB tile over a quarter of the
+// k-steps and the partial sums are exchanged through LDS at the end (reduce-scatter: wave q ends with row q).
+//   * per k-step a wave issues 4 activation reads (LDS) + NTB weight reads for 4*NTB MFMAs (v4: 1 + NTB reads for NTB
+//     MFMAs -- that kernel is LDS-bandwidth bound, its 4 waves all read the same weight fragments);
+//   * a wave's weight fragments are used by that wave only, so they go global -> VGPR directly (1 KiB contiguous per
+//     16-lane group in the packed layout), prefetched two k-steps ahead in three static register sets; no weight ring,
+//     no barrier and no manual waitcnt in the main loop;
+//   * rows are visited in the rotated order (wave + i) & 3 so that the wave's own row has the STATIC register index 0;
+//   * a wave's k-range is padded to a multiple of 3 (the unroll); padding steps read a 16-byte zero slot in LDS as their
+//     activation operand;
+//   * residual / activation-gradient operands and the bias are fetched before the main loop.
+template <typename T, int KS, int NTB>
+__global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
+  constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
+  constexpr int TH = 4;
+  constexpr int TWH = (KS == 3) ? 18 : 16;
+  constexpr int COB = NTB * 16;
+  constexpr int SS = stage_stride(KS, NTB, CB);
+  constexpr int KSB = 4 * COB * CB;  // bytes of one k-step in a stage image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;                     // halo tile; after the main loop: reduce scratch, 12 slots of NTB KiB
+  char* zslot = smem + a.halo_bytes;     // 16 zero bytes
+  float* lbias = reinterpret_cast<float*>(zslot + 16);
+  if (a.dbg & 16) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
+  int n = 0, ty = 0, tx = 0;
+  long long m0 = 0;
+  if (KS == 3) {
+    int bid = blockIdx.x;
+    tx = bid % a.tiles_x;
+    int r = bid / a.tiles_x;
+    ty = r % a.tiles_y;
+    n = r / a.tiles_y;
+  } else {
+    m0 = (long long)blockIdx.x * 64;
+  }
+  if (tid < 4) reinterpret_cast<int*>(zslot)[tid] = 0;
+  if (tid < COB) lbias[tid] = (a.bias && cb * COB + tid < a.Cout) ? a.bias[cb * COB + tid] : 0.f;
+
+  // ---- early fetch of the epilogue operands of this wave's own row
+  const bool fast = conv_epilogue_fast(a);
+  Raw4<T> pre_res[NTB], pre_aux[NTB];
+  {
     long long pix;
-    bool valid;
-    int y = 0, x = 0;
-    if (KS == 3) {
-      y = ty * TH + wave * MT + mt;
-      x = tx * 16 + px;
-      valid = (y < a.H) && (x < a.W);
-      pix = ((long long)n * a.H + y) * a.W + x;
-    } else {
-      pix = m0 + (wave * MT + mt) * 16 + px;
-      valid = pix < a.M;
-      if (a.ps) {
-        x = (int)(pix % a.W);
-        const long long t = pix / a.W;
-        y = (int)(t % a.H);
-        n = (int)(t / a.H);
-      }
-    }
-    if (!valid || (a.dbg & 8)) continue;
-    if (fast) {
+    const bool valid = conv_row_pixel<KS>(a, wave, TH, n, ty, tx, m0, px, pix);
+    if (fast && valid) {
+      const T* res = reinterpret_cast<const T*>(a.res);
+      const T* aux = reinterpret_cast<const T*>(a.aux);
 #pragma unroll
       for (int ct = 0; ct < NTB; ++ct) {
-        if (ct < nt_real) {
-          const int co0 = cb * COB + ct * 16 + g * 4;
-          float v[4] = {acc[ct][mt][0], acc[ct][mt][1], acc[ct][mt][2], acc[ct][mt][3]};
-          if (a.bias) {
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + co0);
-            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-          }
-          if (out_pre) store4(out_pre + pix * a.out_ps + co0, v);
-          if (a.act == VMG_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]) * a.alpha;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * neg) * a.alpha;
-          }
-          if (aux) {
-            float u[4];
-            load4(aux + pix * a.aux_ps + co0, u);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float d = a.actgrad == 3 ? gelu_erf_grad(u[r]) : (u[r] > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
-              v[r] *= d;
-            }
-          }
-          if (res) {
-            float u[4];
-            load4(res + pix * a.res_ps + co0, u);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += u[r];
-          }
-          if (a.ps) {
-            // torch PixelShuffle(2): channel co = c*4 + i*2 + j -> out[n, 2y+i, 2x+j, c]
-            const int c = co0 >> 2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const long long op = ((long long)n * (2 * a.H) + (2 * y + (r >> 1))) * (2 * a.W) + (2 * x + (r & 1));
-              out[op * a.out_ps + c] = from_f32<T>(v[r]);
-            }
-          } else {
-            store4(out + pix * a.out_ps + co0, v);
-          }
-        }
-      }
-      continue;
-    }
-    // general path (Cout not a multiple of 16, or unaligned strides): element-wise with bounds checks
-    for (int ct = 0; ct < nt_real; ++ct) {
-      const int co0 = cb * COB + ct * 16 + g * 4;
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + r;
-        if (co >= a.Cout) continue;
-        float t = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < NTB; ++c2)  // static register index
-          if (c2 == ct) t = r == 0 ? acc[c2][mt][0] : (r == 1 ? acc[c2][mt][1] : (r == 2 ? acc[c2][mt][2] : acc[c2][mt][3]));
-        if (a.bias) t += a.bias[co];
-        if (out_pre) out_pre[pix * a.out_ps + co] = from_f32<T>(t);
-        if (a.act == VMG_ACT_GELU) t = gelu_erf(t) * a.alpha;
-        else t = (t > 0.f ? t : t * neg) * a.alpha;
-        if (aux) {
-          const float u = to_f32(aux[pix * a.aux_ps + co]);
-          t *= a.actgrad == 3 ? gelu_erf_grad(u) : (u > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
-        }
-        if (res) t += to_f32(res[pix * a.res_ps + co]);
-        if (a.ps) {
-          const long long op = ((long long)n * (2 * a.H) + (2 * y + ((co & 3) >> 1))) * (2 * a.W) + (2 * x + (co & 1));
-          out[op * a.out_ps + (co >> 2)] = from_f32<T>(t);
-        } else {
-          out[pix * a.out_ps + co] = from_f32<T>(t);
-        }
+        const int co0 = min(cb * COB + ct * 16 + g * 4, a.Cout - 4);  // tiles beyond nt_real are never used
+        if (res) pre_res[ct].load(res + pix * a.res_ps + co0);
+        if (aux) pre_aux[ct].load(aux + pix * a.aux_ps + co0);
       }
     }
   }
+
+  f32x4 acc[NTB][4];
+#pragma unroll
+  for (int ct = 0; ct < NTB; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const char* wlane = a.wpack + (long long)cb * a.nstages * SS + g * (COB * CB) + px * CB;
+  int st0 = 0;
+  for (int s = 0; s < a.nsrc; ++s) {
+    const int ch = a.src_ch[s], pixb = a.src_pixb[s];
+    const int CH = ch >> 3, nb = (CH + 3) >> 2;
+    if (s > 0) __syncthreads();  // everyone is done reading the previous halo tile
+    stage_halo<T, KS, 1>(a, s, halo, n, ty, tx, m0, tid);
+    __syncthreads();
+
+    const int nks = (a.dbg & 32) ? 0 : (KS == 3 ? 9 * nb : nb);  // k-steps of this source
+    const int per = ((nks + 3) / 4 + 2) / 3 * 3;                 // per wave, padded to the unroll
+    const int k0 = wave * per;
+    const int rowb = TWH * pixb;  // LDS bytes per tile row (KS == 1: TWH = 16 pixels)
+    const char* pixp = halo + px * pixb;
+    int rowoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowoff[i] = ((wave + i) & 3) * rowb;
+
+    Frag<T> wf[3][NTB], xf[3][4];
+    auto load_w = [&](int set, int k) {  // weights of k-step k (clamped: a padding step multiplies them by zeros)
+      const int kc = min(k, nks - 1);
+      long long off;
+      if (KS == 3) {
+        const int cbk = kc / 9, tap = kc - 9 * cbk, ky = tap / 3, kx = tap - 3 * ky;
+        off = (long long)(st0 + cbk * 3 + ky) * SS + kx * KSB;
+      } else {
+        off = (long long)(st0 + (kc >> 1)) * SS + (kc & 1) * KSB;
+      }
+      const char* p = wlane + off;
+#pragma unroll
+      for (int ct = 0; ct < NTB; ++ct) wf[set][ct].load(p + ct * 16 * CB);
+    };
+    auto load_x = [&](int set, int k) {
+      const bool real = k < nks;
+      const int kc = min(k, nks - 1);
+      int boff;
+      if (KS == 3) {
+        const int cbk = kc / 9, tap = kc - 9 * cbk, ky = tap / 3, kx = tap - 3 * ky;
+        boff = ky * rowb + kx * pixb + min(4 * cbk + g, CH - 1) * CB;
+      } else {
+        boff = min(4 * kc + g, CH - 1) * CB;
+      }
+      const char* base = real ? pixp + boff : zslot;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[set][i].load(base + (real ? rowoff[i] : 0));
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+      for (int ct = 0; ct < NTB; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ct][i] = mma(wf[set][ct], xf[set][i], acc[ct][i]);
+    };
+    if (nks > 0) {
+      load_w(0, k0);
+      load_w(1, k0 + 1);
+      load_x(0, k0);
+      for (int k = k0; k < k0 + per; k += 3) {
+        load_w(2, k + 2);
+        load_x(1, k + 1);
+        mfma_set(0);
+        load_w(0, k + 3);
+        load_x(2, k + 2);
+        mfma_set(1);
+        load_w(1, k + 4);
+        load_x(0, k + 3);
+        mfma_set(2);
+      }
+    }
+    st0 += a.src_nst[s];
+  }
+
+  // ---- reduce-scatter of the four partial tiles: slot (q, j) = row q's partial from wave (q + j) & 3, j = 1..3
+  __syncthreads();  // all waves are done with the halo tile
+  char* scratch = smem;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const int q = (wave + i) & 3, j = 4 - i;
+    char* dst = scratch + ((q * 3 + (j - 1)) * NTB) * 1024 + lane * 16;
+#pragma unroll
+    for (int ct = 0; ct < NTB; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 1024) = acc[ct][i];
+  }
+  __syncthreads();
+  f32x4 own[NTB];
+#pragma unroll
+  for (int ct = 0; ct < NTB; ++ct) own[ct] = acc[ct][0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const char* src = scratch + ((wave * 3 + (j - 1)) * NTB) * 1024 + lane * 16;
+#pragma unroll
+    for (int ct = 0; ct < NTB; ++ct) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + ct * 1024);
+      own[ct] += t;
+    }
+  }
+  if (fast) conv_epilogue_row<T, KS, NTB, true>(a, own, wave, TH, cb, nt_real, n, ty, tx, m0, px, g, pre_res, pre_aux, lbias);
+  else conv_epilogue_row<T, KS, NTB, false>(a, own, wave, TH, cb, nt_real, n, ty, tx, m0, px, g);
 }
 
 // ------------------------------------------------------------------------------------------- packing
@@ -502,7 +731,7 @@ int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
   // the dominant kernel class of the path: bf16 3x3, one source of 144 channels, 144 outputs (trajectory chains)
-  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144 && k.M == 16384) && vmg_prof_before(VMG_PROF_CONV3X3, st);
+  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, k);
   if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();
@@ -520,6 +749,39 @@ int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
     case 9: return launch_conv<T, KS, MT, 9, DEEP>(k, ncb, st);
   }
   vmg_set_error("conv: cout_tiles must be 1, 4, 5, 7, 8 or 9 (got %d)", ntb);
+  return -1;
+}
+
+template <typename T, int KS, int NTB>
+int launch_ksplit(const ConvK& k, int ncb, int halo_total, hipStream_t st) {
+  const int scratch = 12 * NTB * 1024;
+  const int lds = (halo_total > scratch ? halo_total : scratch) + 16 + NTB * 16 * 4;
+  VMG_CHECK(lds <= 160 * 1024, "conv (k-split): LDS request %d B exceeds 160 KiB", lds);
+  auto fn = conv_ksplit_kernel<T, KS, NTB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64);
+  VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
+  ConvK kk = k;
+  kk.halo_bytes = lds - 16 - NTB * 16 * 4;  // zero slot and bias sit behind max(halo, scratch)
+  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, kk);
+  if (prof) vmg_prof_after(st);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int KS>
+int dispatch_ksplit(const ConvK& k, int ntb, int ncb, int halo_total, hipStream_t st) {
+  switch (ntb) {
+    case 1: return launch_ksplit<T, KS, 1>(k, ncb, halo_total, st);
+    case 4: return launch_ksplit<T, KS, 4>(k, ncb, halo_total, st);
+    case 5: return launch_ksplit<T, KS, 5>(k, ncb, halo_total, st);
+  }
+  vmg_set_error("conv (k-split): cout_tiles must be 1, 4 or 5 (got %d)", ntb);
   return -1;
 }
 
@@ -614,13 +876,16 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   k.tiles_x = cdiv(d->W, 16); k.tiles_y = cdiv(d->H, TH);
   k.act = d->act; k.slope = d->slope; k.alpha = d->alpha; k.actgrad = d->aux ? d->actgrad : 0; k.ps = d->pixel_shuffle;
   {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("VMG_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-    k.dbg = dbg;
+    const char* e = getenv("VMG_CONV_DBG");  // ablation bits for tools/conv_ablate.py; read per call so one process can sweep
+    k.dbg = e ? atoi(e) : 0;
   }
   k.nstages = kt; k.halo_bytes = (halo + 15) & ~15;
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
+  if (d->deep == 2) {
+    VMG_CHECK(d->dtype == VMG_BF16 && mt == 1, "conv_fwd: the k-split variant is bf16, mt = 1");
+    return d->ks == 3 ? dispatch_ksplit<bf16, 3>(k, ntb, ncb, k.halo_bytes, st) : dispatch_ksplit<bf16, 1>(k, ntb, ncb, k.halo_bytes, st);
+  }
   const bool deep = d->deep != 0;
   if (d->dtype == VMG_BF16) {
     if (d->ks == 3) {

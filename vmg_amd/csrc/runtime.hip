@@ -24,14 +24,14 @@ extern "C" int vmg_max_lds_bytes(void) { return 160 * 1024; }
 namespace {
 struct Prof {
   int klass = 0, stride = 1;
-  long long seen = 0;
+  long long seen = 0, pixels = 0;  // pixels: only launches over exactly this many pixels are timed (0 = any)
   std::vector<hipEvent_t> ev;  // start/stop pairs
   size_t used = 0;
 } g_prof;
 }  // namespace
 
-bool vmg_prof_before(int klass, hipStream_t st) {
-  if (g_prof.klass == 0 || klass != g_prof.klass) return false;
+bool vmg_prof_before(int klass, long long pixels, hipStream_t st) {
+  if (g_prof.klass == 0 || klass != g_prof.klass || (g_prof.pixels != 0 && pixels != g_prof.pixels)) return false;
   if ((g_prof.seen++ % g_prof.stride) != 0 || g_prof.used + 2 > g_prof.ev.size()) return false;
   (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   return true;
@@ -49,6 +49,12 @@ extern "C" int vmg_prof_begin(int klass, int stride, int max_samples) {
     if (hipEventCreate(&e) != hipSuccess) { vmg_set_error("prof_begin: hipEventCreate failed"); return -2; }
     g_prof.ev.push_back(e);
   }
+  return 0;
+}
+
+extern "C" int vmg_prof_select_pixels(int64_t pixels) {
+  VMG_CHECK(pixels >= 0, "prof_select_pixels: negative");
+  g_prof.pixels = pixels;
   return 0;
 }
 

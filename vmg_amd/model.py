@@ -341,41 +341,45 @@ class Trajectory_multi_head(nn.Module):
         self.resblocks = ResidualBlocksWithInputConv(2 * embed_dim, embed_dim, num_blocks, r_scaling)
         self.fusion = nn.Conv2d(3 * embed_dim, embed_dim, 1, 1, 0)
 
-    def _sweep(self, xt, order, flow_of, key_idx):
-        t, n, h, w, c = xt.shape
-        ident = FH.identity_grid(n, h, w, xt.device)
-        feat = None
+    def forward(self, x, flows_forward, flows_backward):
+        """The two direction sweeps of the reference (trajectory.py:323-392 backward, :407-477 forward) share LTAM and
+        resblocks and do not depend on each other, and at sweep step j both hold the same number of key frames
+        (j % stride == 0 marks a key frame in either direction).  They therefore run in LOCKSTEP as one batch of 2n
+        frames -- rows [0, n) are the backward sweep at frame t-1-j, rows [n, 2n) the forward sweep at frame j -- which
+        doubles the pixels per launch of every kernel of the recurrence (M = 2*n*h*w) and halves the launch count."""
+        n, t, h, w, c = x.shape
+        xt = x.transpose(0, 1).contiguous()  # time-major: every frame batch xt[i] is a dense (n,h,w,c) pixel array
+        fb = flows_backward.permute(1, 0, 3, 4, 2).float()
+        ff = flows_forward.permute(1, 0, 3, 4, 2).float()
+        s = self.keyframe_stride
+        xpair = torch.cat([xt.flip(0), xt], 1)  # (t, 2n, h, w, c): step j -> [frame t-1-j | frame j]
+        # step j >= 1 warps by flows_backward[:, t-1-j] (backward sweep) and flows_forward[:, j-1] (forward sweep)
+        flpair = torch.cat([fb.flip(0), ff], 1).contiguous() if t > 1 else None  # (t-1, 2n, h, w, 2); row j-1 serves step j
+        ident = FH.identity_grid(2 * n, h, w, xt.device)
         loc = ident
+        feat = None
         k_in: List[torch.Tensor] = []
         k_state: List[torch.Tensor] = []
-        outs = {}
-        for step, i in enumerate(order):
-            cur = xt[i]
-            if step == 0:
+        feats = []
+        for j in range(t):
+            cur = xpair[j]
+            if j == 0:
                 feat = torch.zeros_like(cur)
             else:
-                fl = flow_of(i)  # (n,h,w,2) fp32
+                fl = flpair[j - 1]
                 feat = flow_warp_nhwc(feat, fl, "bilinear", "border")
                 loc = FH.warp_locations(loc, fl)
                 feat = self.LTAM(cur, k_in, feat, k_state, loc)
-                if i in key_idx:
+                if j % s == 0:
                     loc = torch.cat([loc, ident], 1)
             feat = self.resblocks([cur, feat])
-            if i in key_idx:
+            if j % s == 0:
                 k_state.append(feat)
                 k_in.append(cur)
-            outs[i] = feat
-        return [outs[i] for i in range(t)]
-
-    def forward(self, x, flows_forward, flows_backward):
-        n, t, h, w, c = x.shape
-        xt = x.transpose(0, 1).contiguous()  # time-major: every frame batch xt[i] is a dense (n,h,w,c) pixel array
-        fb = flows_backward.permute(1, 0, 3, 4, 2).float().contiguous()
-        ff = flows_forward.permute(1, 0, 3, 4, 2).float().contiguous()
-        s = self.keyframe_stride
-        back = self._sweep(xt, list(range(t - 1, -1, -1)), lambda i: fb[i], list(range(t - 1, -1, -s)))
-        fwd = self._sweep(xt, list(range(t)), lambda i: ff[i - 1], list(range(0, t, s)))
-        back, fwd = torch.stack(back, 0), torch.stack(fwd, 0)
+            feats.append(feat)
+        outs = torch.stack(feats, 0)  # (t, 2n, h, w, c)
+        back = outs[:, :n].flip(0).contiguous()
+        fwd = outs[:, n:].contiguous()
         out = conv(self.fusion, [back, xt, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
         return out.reshape(t, n, h, w, c).transpose(0, 1).contiguous()
 
