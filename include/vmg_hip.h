@@ -100,6 +100,9 @@ typedef struct vmg_conv_desc {
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
+/* diagnostics: when buf is non-null the k-split variant writes 8 wave-level 100-MHz time stamps per wave
+ * (uint64[workgroups][4][8]) at its phase boundaries; null switches it off */
+int vmg_conv_debug_stamps(void* buf);
 
 /* ------------------------------------------------------------------------------------------------
  * vmg_conv_wgrad -- weight (and bias) gradient of the same convolution, accumulated into fp32 OIHW.

@@ -17,7 +17,7 @@ def main():
         w = torch.randn(Co, Ci, ks, ks, device="cuda") * (Ci * ks * ks) ** -0.5
         b = torch.randn(Co, device="cuda")
         out = torch.empty(N, H, W, Co, device="cuda", dtype=dtype)
-        for tiles in (9, 5):
+        for tiles in (9, 5, 3):
             pw = K.pack_conv_weight(w, dtype, cout_tiles=tiles)
             for mt, deep in ((1, 0), (1, 2)) if tiles <= 5 else ((1, 0),):
                 for _ in range(reps):

@@ -64,7 +64,9 @@ struct ConvK {
   int actgrad, ps;
   int nstages;     // total stages over all sources
   int halo_bytes;  // LDS bytes reserved for the halo tile
-  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop
+  int vec8;        // 1: out / res / aux / out_pre rows are 16-byte aligned with strides % 8 == 0, Cout % 16 == 0, no PixelShuffle
+  unsigned long long* stamps;  // diagnostics: per-wave s_memrealtime stamps (8 per wave) when non-null (vmg_conv_debug_stamps)
+  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop, 64 no k rotation, 128 no XCD-aware tile order
 };
 
 template <typename T>
@@ -98,6 +100,24 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& w, const Frag<float>& x,
   return c;
 }
 
+__device__ uint4 g_conv_zero16;  // 16 zero bytes: the source of out-of-image lanes of the halo copy
+
+// diagnostics: wave-level time stamps (100 MHz constant clock) at phase boundaries of the k-split kernel
+__device__ __forceinline__ void conv_stamp(const ConvK& a, int wave, int slot) {
+  if (a.stamps) {
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + slot] = t;
+  }
+}
+
+// Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Giving XCD j the j-th contiguous
+// eighth of the tile list makes spatially neighbouring tiles (which share halo rows) and both cout blocks of a tile
+// meet in the same L2 (speed only: nothing depends on the placement).  bit 128 of dbg disables it.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk, int dbg) {
+  if ((nblk & 7) != 0 || (dbg & 128)) return bid;
+  return (bid & 7) * (nblk >> 3) + (bid >> 3);
+}
+
 // ---- stage the halo tile of source s in LDS: (THH rows) x (TWH pixels) x ch channels (all 256 threads; no barriers
 // inside -- the caller brackets it)
 template <typename T, int KS, int MT>
@@ -113,35 +133,36 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
       const int vpp = ch * ES / 16;  // 16-byte vectors per pixel
       const float inv_vpp = 1.0f / (float)vpp;
       if (pixb == ch * ES && !(a.dbg & 4)) {
-        // Dense LDS rows: wave w copies rows w, w+4, ... with LDS-DMA (no registers, 1 KiB per instruction); lanes whose
-        // pixel lies outside the image are masked off and write zeros with an ordinary ds_write instead.
-        const int row_vecs = TWH * vpp;
-        for (int r = wave; r < THH; r += 4) {
-          long long rowbase;
-          bool row_ok;
-          int x0;
+        // Dense LDS pixel stride: the tile is ONE linear array of THH*TWH*vpp 16-byte vectors, copied by LDS-DMA (no
+        // registers, 1 KiB per instruction).  Wave w issues instructions w, w+4, ... -- the same count on every wave --
+        // and every lane always loads: a lane whose pixel lies outside the image (or past the end of the tile: the LDS
+        // region is padded to a multiple of 1 KiB) reads a 16-byte zero constant instead.  No branches, no exec masking.
+        const int row_vecs = TWH * vpp, total = THH * row_vecs;
+        const int L0 = wave * 64 + lane;
+        int r = (int)(((float)L0 + 0.5f) * (1.0f / (float)row_vecs));  // exact: L0 < 2^16, row_vecs <= 720
+        int rem = L0 - r * row_vecs;
+        const int dr = 256 / row_vecs, drem = 256 - dr * row_vecs;
+        for (int i0 = wave * 64; i0 < total; i0 += 256) {
+          const int p = (int)(((float)rem + 0.5f) * inv_vpp);  // exact for these ranges (rem < 2^16, vpp <= 40)
+          const int v = rem - p * vpp;
+          bool ok = r < THH;
+          long long goff;
           if (KS == 3) {
-            const int y = ty * TH + r - 1;
-            row_ok = y >= 0 && y < a.H;
-            x0 = tx * 16 - 1;
-            rowbase = (((long long)n * a.H + y) * a.W + x0) * ps_b;
+            const int y = ty * TH + r - 1, x = tx * 16 - 1 + p;
+            ok = ok && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            goff = (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16;
           } else {
-            row_ok = true;
-            x0 = 0;
-            rowbase = (m0 + r * 16) * ps_b;
+            const long long m = m0 + r * 16 + p;
+            ok = ok && m < a.M;
+            goff = m * ps_b + v * 16;
           }
-          char* lrow = halo + r * TWH * pixb;
-          for (int i0 = 0; i0 < row_vecs; i0 += 64) {
-            const int vec = i0 + lane;
-            const int p = (int)(((float)vec + 0.5f) * inv_vpp);  // exact for these ranges (vec < 2^16, vpp <= 40)
-            const int v = vec - p * vpp;
-            bool ok = vec < row_vecs && row_ok;
-            if (KS == 3) ok = ok && (x0 + p >= 0) && (x0 + p < a.W);
-            else ok = ok && (m0 + r * 16 + p < a.M);
-            if (ok) __builtin_amdgcn_global_load_lds(GLB_PTR(sp + rowbase + p * ps_b + v * 16), LDS_PTR(lrow + i0 * 16), 16, 0, 0);
-            else if (vec < row_vecs) *reinterpret_cast<uint4*>(lrow + vec * 16) = make_uint4(0, 0, 0, 0);
-          }
+          const char* gp = ok ? sp + goff : reinterpret_cast<const char*>(&g_conv_zero16);
+          __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(halo + i0 * 16), 16, 0, 0);
+          rem += drem;
+          r += dr;
+          if (rem >= row_vecs) { rem -= row_vecs; ++r; }
         }
+        conv_stamp(a, wave, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         // Padded LDS pixel stride: through registers.  Loads are UNCONDITIONAL (out-of-image lanes read the tensor's
@@ -354,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   int n = 0, ty = 0, tx = 0;
   long long m0 = 0;
   if (KS == 3) {
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x, a.dbg);
     tx = bid % a.tiles_x;
     int r = bid / a.tiles_x;
     ty = r % a.tiles_y;
@@ -457,6 +478,93 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   }
 }
 
+// ---- epilogue of one 16-pixel row through LDS (bf16, ConvK::vec8): the accumulators (per lane 4 channels of a pixel in
+// each of NTB tiles) are written to a wave-private LDS patch as fp32 [pixel][channel] and read back as items of
+// (pixel, 8 consecutive channels), one per lane, so that every global access of the epilogue -- residual, activation
+// -gradient operand, pre-activation and output stores -- is 16 bytes per lane and a pixel's channels leave as whole
+// lines.  The 8-byte stores of the register layout were store-issue bound (16 separate 32-byte segments per instruction).
+template <int NTB>
+struct EpiLds {
+  static constexpr int COB = NTB * 16, C8 = 2 * NTB, PSTR = COB * 4 + 16, NIT = (16 * C8 + 63) / 64;
+  static constexpr int BYTES = 16 * PSTR;
+};
+
+template <int KS, int NTB>
+__device__ __forceinline__ void conv_epilogue_prefetch8(const ConvK& a, int row, int TH, int cb, int n, int ty, int tx, long long m0, int lane,
+                                                        bf16x8 (&pre_res)[EpiLds<NTB>::NIT], bf16x8 (&pre_aux)[EpiLds<NTB>::NIT]) {
+  using E = EpiLds<NTB>;
+  const bf16* res = reinterpret_cast<const bf16*>(a.res);
+  const bf16* aux = reinterpret_cast<const bf16*>(a.aux);
+#pragma unroll
+  for (int it = 0; it < E::NIT; ++it) {
+    const int j = it * 64 + lane, pxi = j / E::C8, c8 = j - pxi * E::C8;
+    long long pix;
+    const bool valid = conv_row_pixel<KS>(a, row, TH, n, ty, tx, m0, pxi & 15, pix);
+    const int co = cb * E::COB + c8 * 8;
+    if (j < 16 * E::C8 && valid && co < a.Cout) {
+      if (res) pre_res[it] = *reinterpret_cast<const bf16x8*>(res + pix * a.res_ps + co);
+      if (aux) pre_aux[it] = *reinterpret_cast<const bf16x8*>(aux + pix * a.aux_ps + co);
+    }
+  }
+}
+
+template <int KS, int NTB>
+__device__ __forceinline__ void conv_epilogue_lds8(const ConvK& a, const f32x4 (&acc)[NTB], char* stg, int row, int TH, int cb, int n, int ty, int tx,
+                                                   long long m0, int lane, const bf16x8 (&pre_res)[EpiLds<NTB>::NIT],
+                                                   const bf16x8 (&pre_aux)[EpiLds<NTB>::NIT], const float* lbias) {
+  using E = EpiLds<NTB>;
+  const int px = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < NTB; ++ct) *reinterpret_cast<f32x4*>(stg + px * E::PSTR + (ct * 16 + g * 4) * 4) = acc[ct];
+  bf16* out = reinterpret_cast<bf16*>(a.out);
+  bf16* out_pre = reinterpret_cast<bf16*>(a.out_pre);
+  const float neg = a.act == VMG_ACT_RELU ? 0.f : (a.act == VMG_ACT_LRELU ? a.slope : 1.f);
+#pragma unroll
+  for (int it = 0; it < E::NIT; ++it) {
+    const int j = it * 64 + lane, pxi = j / E::C8, c8 = j - pxi * E::C8;
+    long long pix;
+    const bool valid = conv_row_pixel<KS>(a, row, TH, n, ty, tx, m0, pxi & 15, pix);
+    const int co = cb * E::COB + c8 * 8;
+    if (!(j < 16 * E::C8 && valid && co < a.Cout) || (a.dbg & 8)) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + pxi * E::PSTR + c8 * 32);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + pxi * E::PSTR + c8 * 32 + 16);
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (a.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(lbias + c8 * 8), b1 = *reinterpret_cast<const f32x4*>(lbias + c8 * 8 + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+    }
+    if (out_pre) {
+      bf16x8 t;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+      *reinterpret_cast<bf16x8*>(out_pre + pix * a.out_ps + co) = t;
+    }
+    if (a.act == VMG_ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]) * a.alpha;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * neg) * a.alpha;
+    }
+    if (a.aux) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float u = (float)pre_aux[it][r];
+        v[r] *= a.actgrad == 3 ? gelu_erf_grad(u) : (u > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+      }
+    }
+    if (a.res) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += (float)pre_res[it][r];
+    }
+    bf16x8 t;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+    *reinterpret_cast<bf16x8*>(out + pix * a.out_ps + co) = t;
+  }
+}
+
 // ================================================================================================ K-split variant
 // Same decomposition of the OUTPUT (64 pixels x NTB*16 channels per workgroup, epilogue row w on wave w), but the four
 // waves split the K loop instead of the pixels: every wave accumulates the whole 64 x COB tile over a quarter of the
@@ -471,7 +579,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 //     activation operand;
 //   * residual / activation-gradient operands and the bias are fetched before the main loop.
 template <typename T, int KS, int NTB>
-__global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
+__global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(const ConvK a) {
   constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
   constexpr int TH = 4;
   constexpr int TWH = (KS == 3) ? 18 : 16;
@@ -492,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
   int n = 0, ty = 0, tx = 0;
   long long m0 = 0;
   if (KS == 3) {
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x, a.dbg);
     tx = bid % a.tiles_x;
     int r = bid / a.tiles_x;
     ty = r % a.tiles_y;
@@ -500,26 +608,16 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
   } else {
     m0 = (long long)blockIdx.x * 64;
   }
+  conv_stamp(a, wave, 0);
   if (tid < 4) reinterpret_cast<int*>(zslot)[tid] = 0;
-  if (tid < COB) lbias[tid] = (a.bias && cb * COB + tid < a.Cout) ? a.bias[cb * COB + tid] : 0.f;
+  // bias: fetched now, written to LDS once the halo has landed (no wait on it here)
+  const float bias_r = (tid < COB && a.bias && cb * COB + tid < a.Cout) ? a.bias[cb * COB + tid] : 0.f;
 
-  // ---- early fetch of the epilogue operands of this wave's own row
-  const bool fast = conv_epilogue_fast(a);
-  Raw4<T> pre_res[NTB], pre_aux[NTB];
-  {
-    long long pix;
-    const bool valid = conv_row_pixel<KS>(a, wave, TH, n, ty, tx, m0, px, pix);
-    if (fast && valid) {
-      const T* res = reinterpret_cast<const T*>(a.res);
-      const T* aux = reinterpret_cast<const T*>(a.aux);
-#pragma unroll
-      for (int ct = 0; ct < NTB; ++ct) {
-        const int co0 = min(cb * COB + ct * 16 + g * 4, a.Cout - 4);  // tiles beyond nt_real are never used
-        if (res) pre_res[ct].load(res + pix * a.res_ps + co0);
-        if (aux) pre_aux[ct].load(aux + pix * a.aux_ps + co0);
-      }
-    }
-  }
+  // ---- early fetch of the epilogue operands of this wave's own row (16-byte path only)
+  constexpr bool BF = std::is_same<T, bf16>::value;
+  const bool vec8 = BF && a.vec8 != 0;
+  bf16x8 pre_res[EpiLds<NTB>::NIT], pre_aux[EpiLds<NTB>::NIT];
+  if (vec8) conv_epilogue_prefetch8<KS, NTB>(a, wave, TH, cb, n, ty, tx, m0, lane, pre_res, pre_aux);
 
   f32x4 acc[NTB][4];
 #pragma unroll
@@ -533,8 +631,12 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
     const int ch = a.src_ch[s], pixb = a.src_pixb[s];
     const int CH = ch >> 3, nb = (CH + 3) >> 2;
     if (s > 0) __syncthreads();  // everyone is done reading the previous halo tile
+    conv_stamp(a, wave, 1);
     stage_halo<T, KS, 1>(a, s, halo, n, ty, tx, m0, tid);
+    if (s == 0 && tid < COB) lbias[tid] = bias_r;
+    conv_stamp(a, wave, 3);
     __syncthreads();
+    conv_stamp(a, wave, 4);
 
     const int nks = (a.dbg & 32) ? 0 : (KS == 3 ? 9 * nb : nb);  // k-steps of this source
     const int per = ((nks + 3) / 4 + 2) / 3 * 3;                 // per wave, padded to the unroll
@@ -579,19 +681,27 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[ct][i] = mma(wf[set][ct], xf[set][i], acc[ct][i]);
     };
+    // Workgroups walk their k-range from different starting points (rotation by block index): at any instant the
+    // 500+ concurrent workgroups then ask L2 for different weight lines instead of all hammering the same channel.
+    const int rot = (a.dbg & 64) ? 0 : (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)per);
+    auto kmap = [&](int i) {  // i-th step of this wave -> k-step index (i >= per: a prefetch past the end, never used)
+      int r = i + rot;
+      r = r >= per ? r - per : r;
+      return k0 + min(r, per - 1);
+    };
     if (nks > 0) {
-      load_w(0, k0);
-      load_w(1, k0 + 1);
-      load_x(0, k0);
-      for (int k = k0; k < k0 + per; k += 3) {
-        load_w(2, k + 2);
-        load_x(1, k + 1);
+      load_w(0, kmap(0));
+      load_w(1, kmap(1));
+      load_x(0, kmap(0));
+      for (int i = 0; i < per; i += 3) {
+        load_w(2, kmap(i + 2));
+        load_x(1, kmap(i + 1));
         mfma_set(0);
-        load_w(0, k + 3);
-        load_x(2, k + 2);
+        load_w(0, kmap(i + 3));
+        load_x(2, kmap(i + 2));
         mfma_set(1);
-        load_w(1, k + 4);
-        load_x(0, k + 3);
+        load_w(1, kmap(i + 4));
+        load_x(0, kmap(i + 3));
         mfma_set(2);
       }
     }
@@ -599,6 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
   }
 
   // ---- reduce-scatter of the four partial tiles: slot (q, j) = row q's partial from wave (q + j) & 3, j = 1..3
+  conv_stamp(a, wave, 5);
   __syncthreads();  // all waves are done with the halo tile
   char* scratch = smem;
 #pragma unroll
@@ -621,8 +732,15 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_kernel(const ConvK a) {
       own[ct] += t;
     }
   }
-  if (fast) conv_epilogue_row<T, KS, NTB, true>(a, own, wave, TH, cb, nt_real, n, ty, tx, m0, px, g, pre_res, pre_aux, lbias);
-  else conv_epilogue_row<T, KS, NTB, false>(a, own, wave, TH, cb, nt_real, n, ty, tx, m0, px, g);
+  conv_stamp(a, wave, 6);
+  if (vec8) {
+    // staging patch = the scratch slots only this wave reads (its reads above have completed: their data is in `own`)
+    static_assert(EpiLds<NTB>::BYTES <= 3 * NTB * 1024, "epilogue staging patch must fit the wave's own scratch slots");
+    conv_epilogue_lds8<KS, NTB>(a, own, scratch + (wave * 3 * NTB) * 1024, wave, TH, cb, n, ty, tx, m0, lane, pre_res, pre_aux, lbias);
+  } else {
+    conv_epilogue_row<T, KS, NTB, false>(a, own, wave, TH, cb, nt_real, n, ty, tx, m0, px, g);
+  }
+  conv_stamp(a, wave, 7);
 }
 
 // ------------------------------------------------------------------------------------------- packing
@@ -742,13 +860,14 @@ template <typename T, int KS, int MT, bool DEEP>
 int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
   switch (ntb) {
     case 1: return launch_conv<T, KS, MT, 1, DEEP>(k, ncb, st);
+    case 3: return launch_conv<T, KS, MT, 3, DEEP>(k, ncb, st);
     case 4: return launch_conv<T, KS, MT, 4, DEEP>(k, ncb, st);
     case 5: return launch_conv<T, KS, MT, 5, DEEP>(k, ncb, st);
     case 7: return launch_conv<T, KS, MT, 7, DEEP>(k, ncb, st);
     case 8: return launch_conv<T, KS, MT, 8, DEEP>(k, ncb, st);
     case 9: return launch_conv<T, KS, MT, 9, DEEP>(k, ncb, st);
   }
-  vmg_set_error("conv: cout_tiles must be 1, 4, 5, 7, 8 or 9 (got %d)", ntb);
+  vmg_set_error("conv: cout_tiles must be 1, 3, 4, 5, 7, 8 or 9 (got %d)", ntb);
   return -1;
 }
 
@@ -778,14 +897,21 @@ template <typename T, int KS>
 int dispatch_ksplit(const ConvK& k, int ntb, int ncb, int halo_total, hipStream_t st) {
   switch (ntb) {
     case 1: return launch_ksplit<T, KS, 1>(k, ncb, halo_total, st);
+    case 3: return launch_ksplit<T, KS, 3>(k, ncb, halo_total, st);
     case 4: return launch_ksplit<T, KS, 4>(k, ncb, halo_total, st);
     case 5: return launch_ksplit<T, KS, 5>(k, ncb, halo_total, st);
   }
-  vmg_set_error("conv (k-split): cout_tiles must be 1, 4 or 5 (got %d)", ntb);
+  vmg_set_error("conv (k-split): cout_tiles must be 1, 3, 4 or 5 (got %d)", ntb);
   return -1;
 }
 
 }  // namespace
+
+static unsigned long long* g_conv_stamps = nullptr;
+extern "C" int vmg_conv_debug_stamps(void* buf) {  // diagnostics only (tools/conv_timeline.py); buf: 8 * 4 * workgroups uint64, or null
+  g_conv_stamps = (unsigned long long*)buf;
+  return 0;
+}
 
 extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles) {
   short xoff[MAX_ISRC], xch[MAX_ISRC];
@@ -878,8 +1004,15 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   {
     const char* e = getenv("VMG_CONV_DBG");  // ablation bits for tools/conv_ablate.py; read per call so one process can sweep
     k.dbg = e ? atoi(e) : 0;
+    k.stamps = g_conv_stamps;
   }
-  k.nstages = kt; k.halo_bytes = (halo + 15) & ~15;
+  {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    k.vec8 = d->dtype == VMG_BF16 && !d->pixel_shuffle && (d->Cout % 16) == 0 && (d->out_ps % 8) == 0 && al(d->out) &&
+             (!d->out_pre || al(d->out_pre)) && (!d->res || ((d->res_ps % 8) == 0 && al(d->res))) &&
+             (!d->aux || ((d->aux_ps % 8) == 0 && al(d->aux)));
+  }
+  k.nstages = kt; k.halo_bytes = (halo + 1023) & ~1023;  // the LDS-DMA copy writes whole 1-KiB pieces
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
   if (d->deep == 2) {
