@@ -26,10 +26,11 @@ def _pad_to(n: int, m: int = 8) -> int:
 
 def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
     """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3, kernel
-    durations): the 144-channel 3x3 convs run best as 64-pixel x 80-channel workgroups (two cout blocks) with the 2-slot
-    weight ring, whose small LDS footprint puts two workgroups on a CU: 16.8 us at M = 16 384, 100 us at M = 114 688."""
+    durations): the 144-channel 3x3 convs run best on the K-split kernel (deep = 2) as 64-pixel x 48-channel workgroups
+    (three cout blocks, no padded tile, 138 registers -> three workgroups per CU): 25 us at M = 32 768 (27 us with two
+    blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
     if dtype == torch.bfloat16 and ks == 3 and cout == 144:
-        return 5, 1, 2
+        return 3, 1, 2
     return None, 1, 0
 
 
