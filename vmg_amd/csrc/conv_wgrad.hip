@@ -381,49 +381,73 @@ __global__ __launch_bounds__(W2_THREADS) void conv_wgrad2_kernel(const Wgrad2K a
   const bf16 one = (bf16)1.0f;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
-  auto issue = [&](long long ug, int buf) {
-    const int pair = (int)(ug / a.Upair);
-    const long long u = ug - (long long)pair * a.Upair;
-    const int seg = (int)(u % a.SEG);
-    const long long r = u / a.SEG;
-    const int y = (int)(r % a.H), n = (int)(r / a.H);
-    const int x0 = seg * 32;
+  // Lane constants of the two tile copies: which vector of the tile a lane moves never changes, only the unit does.
+  const int p_dy = tid / 18, v_dy = tid - p_dy * 18;
+  const bool c_dy = ob + v_dy * 8 + 8 <= a.Cout;
+  const int off_dy = (int)((p_dy * a.dy_ps + ob + v_dy * 8) * 2);
+  int off_x[2], rr_x[2], col_x[2];
+  bool c_x[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = 64 * i + lane, vec = W2_XVW * wave + k;
+    const int pp = vec / 6, v = vec - pp * 6;
+    rr_x[i] = pp / W2_XW;
+    col_x[i] = pp - rr_x[i] * W2_XW;
+    c_x[i] = k < W2_XVW && vec < W2_XVEC && (ib + v * 8 + 8 <= a.Cin);
+    off_x[i] = (int)((((long long)(rr_x[i] - 1) * a.W + (col_x[i] - 1)) * a.x_ps + ib + v * 8) * 2);
+  }
+  const bool x_tail = W2_XVW * wave + 64 < W2_XVEC && W2_XVW > 64;  // (wave-uniform) the wave's second X instruction has lanes to move
+  // The unit to issue next, as (pair, image, row, 32-pixel segment): decoded once, then advanced like an odometer (all
+  // wave-uniform scalar work; the per-unit divisions of a flat index cost more than the MFMAs they fed).
+  int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
+  {
+    const long long uu = u_lo - (long long)ipair * a.Upair;
+    iseg = (int)(uu % a.SEG);
+    const long long r = uu / a.SEG;
+    iy = (int)(r % a.H);
+    in_ = (int)(r / a.H);
+  }
+  auto issue = [&](int buf) {
+    const int x0 = iseg * 32;
+    const long long row = ((long long)in_ * a.H + iy) * a.W + x0;  // first pixel of the unit
     char* dyt = smem + buf * W2_BUF;
     char* xt = dyt + W2_DY_BYTES;
-    {  // dY tile: 576 vectors, one per thread: pixel p, 8-channel vector v
-      const int p = tid / 18, v = tid - p * 18;
-      const int c = ob + v * 8;
-      const bool ok = (x0 + p < a.W) && (c + 8 <= a.Cout);
-      const char* src = ok ? a.dy[pair] + ((((long long)n * a.H + y) * a.W + x0 + p) * a.dy_ps + c) * 2 : zsrc;
+    {  // dY tile: 576 vectors, one per thread
+      const bool ok = c_dy && (x0 + p_dy < a.W);
+      const char* src = ok ? a.dy[ipair] + row * a.dy_ps * 2 + off_dy : zsrc;
       __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dyt + wave * 1024), 16, 0, 0);
     }
+    const char* xrow = a.x[ipair] + row * a.x_ps * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {  // X tile: this wave's share of 68 vectors in two instructions
-      const int k = 64 * i + lane;
-      const int vec = W2_XVW * wave + k;
-      if (k < W2_XVW && vec < W2_XVEC) {
-        const int p = vec / 6, v = vec - p * 6;
-        const int rr = p / W2_XW, col = p - rr * W2_XW;
-        const int yy = y + rr - 1, xx = x0 + col - 1;
-        const int c = ib + v * 8;
-        const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && (c + 8 <= a.Cin);
-        const char* src = ok ? a.x[pair] + ((((long long)n * a.H + yy) * a.W + xx) * a.x_ps + c) * 2 : zsrc;
+    for (int i = 0; i < 2; ++i) {  // X tile: this wave's share of 68 vectors in two instructions (64 + 4 lanes)
+      if (i == 1 && !x_tail) break;
+      const int yy = iy + rr_x[i] - 1, xx = x0 + col_x[i] - 1;
+      const bool ok = c_x[i] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const char* src = ok ? xrow + off_x[i] : zsrc;
+      if (i == 0 || (64 + lane < W2_XVW && W2_XVW * wave + 64 + lane < W2_XVEC))
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(xt + (W2_XVW * wave + 64 * i) * 16), 16, 0, 0);
+    }
+    if (++iseg == a.SEG) {
+      iseg = 0;
+      if (++iy == a.H) {
+        iy = 0;
+        if (++in_ == a.N) { in_ = 0; ++ipair; }
       }
     }
   };
 
-  if (u_lo < u_hi) issue(u_lo, 0);
+  // Three LDS buffers, ONE barrier per unit.  At the top of iteration u a wave waits for its own share of unit u (issued
+  // two iterations ago), then the barrier tells it that (a) every wave's share of unit u has landed and (b) every wave has
+  // finished reading unit u-1 (each drains its LDS reads before arriving) -- so unit u+2 may now overwrite u-1's buffer.
+  if (u_lo < u_hi) issue(0);
+  if (u_lo + 1 < u_hi) issue(1);
+  int buf = 0;
   for (long long u = u_lo; u < u_hi; ++u) {
-    const int buf = (int)((u - u_lo) & 1);
-    if (u + 1 < u_hi) {
-      issue(u + 1, buf ^ 1);  // its buffer was last read in iteration u-1; everyone passed that iteration's closing barrier
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u landed; unit u+1 (3 instructions per wave) stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (u + 1 < u_hi) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u landed; unit u+1 (3 instructions per wave) stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (u + 2 < u_hi) issue(buf == 0 ? 2 : buf - 1);
     const char* dyt = smem + buf * W2_BUF;
     const char* xt = dyt + W2_DY_BYTES;
     bf16x8 af[3];
@@ -440,9 +464,8 @@ __global__ __launch_bounds__(W2_THREADS) void conv_wgrad2_kernel(const Wgrad2K a
 #pragma unroll
       for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // all waves are done reading this buffer
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit u are complete before it arrives at the next barrier
+    buf = buf == 2 ? 0 : buf + 1;
   }
   // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
   float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W2_WAVES + wave) * (W2_TILES * 256);
@@ -518,7 +541,7 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
   k.S = (int)S; k.slab = (float*)ws;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 2 * W2_BUF, st, k);
+  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * W2_BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
   const int rb = (int)(cdiv64(per_s, 256) > 2048 ? 2048 : cdiv64(per_s, 256));
