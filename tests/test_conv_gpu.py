@@ -283,3 +283,33 @@ def test_conv_ksplit_concat_linear_and_repeatability():
     for _ in range(20):
         again = K.conv_forward([xb], pw2, None, 8, 64, 64, deep=2)[0]
         assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3000, 144, 144, 3), (2, 33, 37, 144, 576, 2), (1, 64, 64, 576, 144, 1), (1, 50, 41, 112, 224, 4),
+                                   (4, 64, 64, 432, 144, 2), (1, 1, 2500, 8, 24, 1)])
+def test_linear_wgrad_batched_large_tile(shape):
+    """bf16 1x1 / Linear batched weight gradient = the GEMM-over-pixels kernel (transposed LDS reads, slabs + ordered
+    reduction): sum over pairs of autograd gradients, accumulated into a slice of a wider dW and into db, bitwise
+    reproducible; ragged pixel counts and channel counts that are not multiples of the 144-wide tile."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, P = shape
+    dt = torch.bfloat16
+    M = N * H * W
+    xs = [R.seeded((M, Ci), 140 + p) for p in range(P)]
+    dys = [R.seeded((M, Co), 160 + p) for p in range(P)]
+    gw = sum(_q(d, dt).t().double() @ _q(x, dt).double() for x, d in zip(xs, dys)).float()
+    gb = sum(_q(d, dt).double().sum(0) for d in dys).float()
+    I_total, i0 = Ci + 16, 8
+    init_w, init_b = R.seeded((Co, I_total), 180), R.seeded((Co,), 181)
+    xd, dd = [x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys]
+    outs = []
+    for rep in range(2):
+        dW, db = init_w.clone().cuda(), init_b.clone().cuda()
+        K.conv_wgrad_batched(xd, dd, dW, db, 1, N, H, W, scale=0.5, i0=i0)
+        outs.append((dW.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want = init_w.clone()
+    want[:, i0:i0 + Ci] += 0.5 * gw
+    scale = max(1.0, float(gw.abs().max()))
+    assert float((outs[0][0] - want).abs().max()) <= 2e-3 * scale
+    assert float((outs[0][1] - (init_b + 0.5 * gb)).abs().max()) <= 2e-3 * max(1.0, float(gb.abs().max()))

@@ -482,14 +482,40 @@ __global__ __launch_bounds__(W2_THREADS) void conv_wgrad2_kernel(const Wgrad2K a
   }
 }
 
+// Sum of element i over the S slabs, in a FIXED order (deterministic): the block's 4 waves each take the slabs
+// s = w, w+4, ... (coalesced 256-byte rows, 4 loads in flight), the 4 partial sums are combined through LDS as
+// ((p0 + p1) + (p2 + p3)).  Call with blockDim = 256; lane l of every wave works on element i0 + l; returns the sum on
+// wave 0 (other waves get an unspecified value).
+__device__ __forceinline__ float slab_sum_4waves(const float* __restrict__ slab, long long per_s, int S, long long i, bool valid, float* red) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (valid) {
+    int s = w;
+    for (; s + 12 < S; s += 16) {
+      a0 += slab[(long long)s * per_s + i];
+      a1 += slab[(long long)(s + 4) * per_s + i];
+      a2 += slab[(long long)(s + 8) * per_s + i];
+      a3 += slab[(long long)(s + 12) * per_s + i];
+    }
+    for (; s < S; s += 4) a0 += slab[(long long)s * per_s + i];
+  }
+  red[w * 64 + l] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  const float r = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+  __syncthreads();
+  return r;
+}
+
 // sums the S slabs in order and adds into dW / db
 __global__ __launch_bounds__(256) void conv_wgrad2_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
                                                                  float* __restrict__ dW, int I_total, int o0, int i0,
                                                                  float* __restrict__ db, float scale) {
+  __shared__ float red[256];
   const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < per_s; i += (long long)gridDim.x * 256) {
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += slab[s * per_s + i];
+  for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {  // per_s is a multiple of 256
+    const long long i = e0 + (threadIdx.x & 63);
+    const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
+    if (threadIdx.x >= 64) continue;
     // decode i -> (ciblk, coblk, wave, tile, lane, r)
     const int r = (int)(i & 3);
     const int lane = (int)((i >> 2) & 63);
@@ -513,6 +539,135 @@ __global__ __launch_bounds__(256) void conv_wgrad2_reduce_kernel(const float* __
   }
 }
 
+// =====================================================================================================
+// v2 for 1x1 convolutions / Linears (bf16): dW[co][ci] = sum_p dY[p][co] * X[p][ci], a GEMM whose K is the pixel list.
+// Workgroup = 9 waves (cg, it); output tile 144 co x 144 ci, wave (cg, it) owns co tiles 3cg..3cg+2 x ci tiles 3it..3it+2
+// (9 accumulator tiles + the bias tile for it == 0).  A unit = 32 consecutive pixels of the flat pixel list: both tiles
+// ([32][144] bf16, 9 KiB each) arrive by LDS-DMA exactly as they lie in HBM, one 16-byte vector per thread and tile, and
+// are read TRANSPOSED (ds_read_b64_tr_b16).  Three LDS buffers, one barrier per unit (see the 3x3 kernel above); the LDS
+// footprint (54 KiB) and register use allow two workgroups per CU, whose barrier bubbles overlap.  The pixel list is
+// cut into S slabs; partial tiles go to the workspace and the reduce kernel adds them to dW in slab order.
+struct Lgrad2K {
+  const char* x[WG_MAX_PAIRS];
+  const char* dy[WG_MAX_PAIRS];
+  int npairs;
+  long long Mpair;   // pixels per pair
+  long long Upair, U;  // 32-pixel units per pair / in total
+  long long x_ps, dy_ps;
+  int Cin, Cout;
+  float* slab;  // [S][ciblk][coblk][9 waves][10 tiles][64][4]
+  int S, has_bias;
+};
+constexpr int L2_TILE_BYTES = 32 * 144 * 2;  // 9216
+constexpr int L2_BUF = 2 * L2_TILE_BYTES;    // dY tile + X tile
+constexpr int L2_TILES = 10;
+constexpr long long L2_WG_FLOATS = (long long)W2_WAVES * L2_TILES * 256;
+
+__global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgrad2K a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = wave / 3, it = wave - cg * 3;
+  const int ob = blockIdx.x * 144, ib = blockIdx.y * 144;
+  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
+
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  // lane constants: thread tid moves vector v (8 channels) of pixel p of both tiles
+  const int p_l = tid / 18, v_l = tid - p_l * 18;
+  const bool c_dy = ob + v_l * 8 + 8 <= a.Cout, c_x = ib + v_l * 8 + 8 <= a.Cin;
+  const int off_dy = (int)((p_l * a.dy_ps + ob + v_l * 8) * 2), off_x = (int)((p_l * a.x_ps + ib + v_l * 8) * 2);
+  int ipair = (int)(u_lo / a.Upair);
+  long long ipix = (u_lo - (long long)ipair * a.Upair) * 32;  // first pixel (within the pair) of the unit to issue next
+  auto issue = [&](int buf) {
+    const bool pok = ipix + p_l < a.Mpair;
+    char* dyt = smem + buf * L2_BUF;
+    const char* s0 = (pok && c_dy) ? a.dy[ipair] + ipix * a.dy_ps * 2 + off_dy : zsrc;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(s0), LDS_PTR(dyt + wave * 1024), 16, 0, 0);
+    const char* s1 = (pok && c_x) ? a.x[ipair] + ipix * a.x_ps * 2 + off_x : zsrc;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(s1), LDS_PTR(dyt + L2_TILE_BYTES + wave * 1024), 16, 0, 0);
+    ipix += 32;
+    if (ipix >= a.Mpair) { ipix = 0; ++ipair; }
+  };
+
+  if (u_lo < u_hi) issue(0);
+  if (u_lo + 1 < u_hi) issue(1);
+  int buf = 0;
+  for (long long u = u_lo; u < u_hi; ++u) {
+    if (u + 1 < u_hi) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // unit u landed; unit u+1 (2 instructions per wave) stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (u + 2 < u_hi) issue(buf == 0 ? 2 : buf - 1);
+    const char* dyt = smem + buf * L2_BUF;
+    const char* xt = dyt + L2_TILE_BYTES;
+    bf16x8 af[3], bfg[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) af[c] = tr_frag(dyt, 288, 0, (cg * 3 + c) * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bfg[j] = tr_frag(xt, 288, 0, (it * 3 + j) * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[j], acc[c][j], 0, 0, 0);
+    if (a.has_bias && it == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W2_WAVES + wave) * (L2_TILES * 256);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(sl + ((c * 3 + j) * 64 + lane) * 4) = acc[c][j];
+  if (a.has_bias && it == 0 && blockIdx.y == 0) {
+    f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15;
+    if (l15 < 3) pack = l15 == 0 ? accb[0] : (l15 == 1 ? accb[1] : accb[2]);
+    *reinterpret_cast<f32x4*>(sl + (9 * 64 + lane) * 4) = pack;
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
+                                                                   float* __restrict__ dW, int I_total, int o0, int i0,
+                                                                   float* __restrict__ db, float scale) {
+  __shared__ float red[256];
+  const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
+  for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
+    const long long i = e0 + (threadIdx.x & 63);
+    const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
+    if (threadIdx.x >= 64) continue;
+    const int r = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    long long q = i >> 8;
+    const int tile = (int)(q % L2_TILES);
+    q /= L2_TILES;
+    const int wave = (int)(q % W2_WAVES);
+    q /= W2_WAVES;
+    const int coblk = (int)(q % gx), ciblk = (int)(q / gx);
+    const int cg = wave / 3, it = wave - cg * 3;
+    const int g = lane >> 4, l15 = lane & 15;
+    if (tile < 9) {
+      const int c = tile / 3, j = tile - c * 3;
+      const int co = coblk * 144 + (cg * 3 + c) * 16 + 4 * g + r;
+      const int ci = ciblk * 144 + (it * 3 + j) * 16 + l15;
+      if (co < Cout && ci < Cin) dW[(long long)(o0 + co) * I_total + (i0 + ci)] += sum * scale;
+    } else if (db && it == 0 && ciblk == 0 && l15 < 3) {
+      const int co = coblk * 144 + (cg * 3 + l15) * 16 + 4 * g + r;
+      if (co < Cout) db[o0 + co] += sum * scale;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W2_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~83 MB)
@@ -520,6 +675,33 @@ extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W2_WG_FLOATS *
 extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
                                          int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0,
                                          float* db, float scale, void* ws, int64_t ws_bytes, void* stream) {
+  if (ws && dtype == VMG_BF16 && ks == 1 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
+      (Cin % 8 == 0) && (Cout % 8 == 0) && x_ps >= Cin && dy_ps >= Cout && N > 0 && H > 0 && W > 0 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0) {
+    bool al = true;
+    for (int p = 0; al && p < npairs; ++p) al = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
+    Lgrad2K k;
+    memset(&k, 0, sizeof(k));
+    k.Mpair = (long long)N * H * W;
+    k.Upair = (k.Mpair + 31) / 32; k.U = k.Upair * npairs;
+    const int gx = cdiv(Cout, 144), gy = cdiv(Cin, 144);
+    long long S = 512 / ((long long)gx * gy);  // two workgroups per CU
+    if (S > k.U / 8) S = k.U / 8;
+    if (S < 1) S = 1;
+    const long long need = S * gx * gy * L2_WG_FLOATS * 4;
+    if (al && need <= ws_bytes && k.U >= 64) {  // (tiny problems: the v1 kernel's single launch is cheaper)
+      for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
+      k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.S = (int)S; k.slab = (float*)ws;
+      k.has_bias = db != nullptr;
+      hipStream_t st = (hipStream_t)stream;
+      hipLaunchKernelGGL(linear_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * L2_BUF, st, k);
+      VMG_LAUNCH_CHECK();
+      const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
+      const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
+      hipLaunchKernelGGL(linear_wgrad2_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
+      VMG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // the large-tile path needs bf16, 3x3, 16-byte aligned 8-channel vectors; anything else takes the v1 kernel
   bool ok = ws && dtype == VMG_BF16 && ks == 3 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
             (Cin % 8 == 0) && (Cout % 8 == 0);
@@ -544,7 +726,7 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * W2_BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
-  const int rb = (int)(cdiv64(per_s, 256) > 2048 ? 2048 : cdiv64(per_s, 256));
+  const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
   hipLaunchKernelGGL(conv_wgrad2_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
   VMG_LAUNCH_CHECK();
   return 0;
