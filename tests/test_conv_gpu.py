@@ -313,3 +313,18 @@ def test_linear_wgrad_batched_large_tile(shape):
     scale = max(1.0, float(gw.abs().max()))
     assert float((outs[0][0] - want).abs().max()) <= 2e-3 * scale
     assert float((outs[0][1] - (init_b + 0.5 * gb)).abs().max()) <= 2e-3 * max(1.0, float(gb.abs().max()))
+
+
+def test_conv_ksplit_pixel_shuffle():
+    """PixelShuffle(2) + LeakyReLU fused in the K-split kernel's epilogue (the upsampling head, models/vmg.py:629-630)."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, C = 2, 12, 20, 144
+    x = R.seeded((N, H, W, C), 14)
+    w = R.seeded((4 * C, C, 3, 3), 15, (C * 9) ** -0.5)
+    b = R.seeded((4 * C,), 16, 0.1)
+    want = F.leaky_relu(O.pixel_shuffle_nhwc(O.conv_nhwc(_q(x, dtype), _q(w, dtype), b, 1)), 0.1)
+    pw = K.pack_conv_weight(w.cuda(), dtype, cout_tiles=3)
+    got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1, pixel_shuffle=True, deep=2)
+    assert tuple(got.shape) == (N, 2 * H, 2 * W, C)
+    _cmp(got, want, dtype, "k-split pixel shuffle conv")

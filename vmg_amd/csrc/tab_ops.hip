@@ -14,47 +14,57 @@ struct V16 {
 
 // ------------------------------------------------------------------------------------------------ reduction
 // mode 0: out[g,c] += scale * sum_r (a [+ b + c3])[g,r,c]      mode 1: out[g,c] += scale * sum_r a*b
-// Threads run along channel PAIRS (4-byte loads for bf16, 8-byte for fp32), 256/tpr rows per block iteration; the
-// row-parallel partials are combined in LDS and added to the zero-initialised output with one float atomic per channel
-// and block.
-template <typename T>
+// Threads run along 16-byte channel vectors (VN = 8 bf16 / 4 fp32 channels; VN = 2 when C is not a multiple of that),
+// 256/tpr rows per block iteration; the row-parallel partials are combined in LDS and added to the zero-initialised
+// output with one float atomic per channel and block.
+template <typename T, int VN>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c3,
                                                            float* __restrict__ out, int G, long long R, int C, int mode, float scale,
                                                            int chunks) {
-  __shared__ float red[2 * 256];
+  struct alignas(sizeof(T) * VN) Vec { T v[VN]; };
+  __shared__ float red[VN * 256];
   const int g = blockIdx.x / chunks, ck = blockIdx.x - g * chunks;
-  const int tpr = C >> 1;           // threads per row
+  const int tpr = C / VN;           // threads per row
   const int rpb = 256 / tpr;        // rows per block iteration
   const int roff = threadIdx.x / tpr, cp = threadIdx.x - roff * tpr;
   const long long r0 = R * ck / chunks, r1 = R * (ck + 1) / chunks;
-  float s0 = 0.f, s1 = 0.f;
+  float s[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) s[e] = 0.f;
   if (roff < rpb) {
-    const long long base = (long long)g * R * C + 2 * cp;
+    const long long base = (long long)g * R * C + VN * cp;
     for (long long r = r0 + roff; r < r1; r += rpb) {
       const long long o = base + r * C;
-      float x0 = to_f32(a[o]), x1 = to_f32(a[o + 1]);
+      const Vec va = *reinterpret_cast<const Vec*>(a + o);
       if (mode == 0) {
-        if (b) { x0 += to_f32(b[o]); x1 += to_f32(b[o + 1]); }
-        if (c3) { x0 += to_f32(c3[o]); x1 += to_f32(c3[o + 1]); }
+        if (b && c3) {
+          const Vec vb = *reinterpret_cast<const Vec*>(b + o), vc = *reinterpret_cast<const Vec*>(c3 + o);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) + to_f32(vb.v[e]) + to_f32(vc.v[e]);
+        } else if (b) {
+          const Vec vb = *reinterpret_cast<const Vec*>(b + o);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) + to_f32(vb.v[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]);
+        }
       } else {
-        x0 *= to_f32(b[o]);
-        x1 *= to_f32(b[o + 1]);
+        const Vec vb = *reinterpret_cast<const Vec*>(b + o);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) * to_f32(vb.v[e]);
       }
-      s0 += x0;
-      s1 += x1;
     }
   }
-  red[2 * threadIdx.x] = s0;
-  red[2 * threadIdx.x + 1] = s1;
+#pragma unroll
+  for (int e = 0; e < VN; ++e) red[e * 256 + threadIdx.x] = s[e];
   __syncthreads();
-  if (threadIdx.x < tpr) {
-    float t0 = 0.f, t1 = 0.f;
-    for (int k = 0; k < rpb; ++k) {
-      t0 += red[2 * (k * tpr + threadIdx.x)];
-      t1 += red[2 * (k * tpr + threadIdx.x) + 1];
-    }
-    atomicAdd(out + (long long)g * C + 2 * threadIdx.x, t0 * scale);
-    atomicAdd(out + (long long)g * C + 2 * threadIdx.x + 1, t1 * scale);
+  // C threads, one per channel: channel c = VN * cp2 + e sums the rpb row partials of column thread cp2
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int cp2 = c / VN, e = c - cp2 * VN;
+    float t = 0.f;
+    for (int k = 0; k < rpb; ++k) t += red[e * 256 + k * tpr + cp2];
+    atomicAdd(out + (long long)g * C + c, t * scale);
   }
 }
 
@@ -147,12 +157,22 @@ extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const v
   if (chunks < 1) chunks = 1;
   if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VMG_BF16)
-    hipLaunchKernelGGL(group_reduce_kernel<bf16>, dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out, G,
-                       (long long)R, C, mode, scale, chunks);
-  else
-    hipLaunchKernelGGL(group_reduce_kernel<float>, dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3, out,
-                       G, (long long)R, C, mode, scale, chunks);
+  const bool al16 = ((uintptr_t)a % 16 == 0) && (!b || (uintptr_t)b % 16 == 0) && (!c3 || (uintptr_t)c3 % 16 == 0);
+  if (dtype == VMG_BF16) {
+    if (C % 8 == 0 && al16)
+      hipLaunchKernelGGL((group_reduce_kernel<bf16, 8>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out,
+                         G, (long long)R, C, mode, scale, chunks);
+    else
+      hipLaunchKernelGGL((group_reduce_kernel<bf16, 2>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out,
+                         G, (long long)R, C, mode, scale, chunks);
+  } else {
+    if (C % 4 == 0 && al16)
+      hipLaunchKernelGGL((group_reduce_kernel<float, 4>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3,
+                         out, G, (long long)R, C, mode, scale, chunks);
+    else
+      hipLaunchKernelGGL((group_reduce_kernel<float, 2>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3,
+                         out, G, (long long)R, C, mode, scale, chunks);
+  }
   VMG_LAUNCH_CHECK();
   return 0;
 }

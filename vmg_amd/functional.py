@@ -29,8 +29,8 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
     durations): the 144-channel 3x3 convs run best on the K-split kernel (deep = 2) as 64-pixel x 48-channel workgroups
     (three cout blocks, no padded tile, 138 registers -> three workgroups per CU): 25 us at M = 32 768 (27 us with two
     blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
-    if dtype == torch.bfloat16 and ks == 3 and cout == 144:
-        return 3, 1, 2
+    if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
+        return 3, 1, 2  # 288 (local_cnn): 151 us vs 247 us at 144 -> 288, M = 114 688; the 576-channel PixelShuffle convs were slower this way
     return None, 1, 0
 
 
