@@ -209,6 +209,17 @@ int vmg_prof_select_pixels(int64_t pixels);
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);
 
+/* ---- sliding-window inference accumulators (reference: tools/Tester.py:107-177, :249-250) --------------------------
+ * vmg_tile_accumulate: for a tile `patch` (planes, ph, pw; dtype 0 = f32, 1 = bf16) placed at (oh, ow) of the fp32
+ * canvases E and Wt (planes, EH, EW):  E += patch * m,  Wt += m, where m drops the first `top` / last `bottom` rows and
+ * the first `left` / last `right` columns of the tile (replaces Tester.test_image's four in-place border zeroings of
+ * out_patch and out_patch_mask and its two slice adds, tools/Tester.py:126-139).
+ * vmg_tile_finalize: q = E / Wt (tools/Tester.py:139); out_f32 (optional) = q; out_u8 (optional) =
+ * round-half-even(clamp(q, 0, 1) * 255) (tools/Tester.py:249-250). */
+int vmg_tile_accumulate(int dtype, const void* patch, float* E, float* Wt, int64_t planes, int ph, int pw, int EH, int EW, int oh, int ow,
+                        int top, int bottom, int left, int right, void* stream);
+int vmg_tile_finalize(const float* E, const float* Wt, float* out_f32, unsigned char* out_u8, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,6 +238,57 @@ case("vmg_tiny_swin")(_vmg_case(lambda T: cfg_tiny_few(T, temporal_empty=False),
 case("vmg_reds_few_cfg1")(_vmg_case(cfg_reds_few, 5, 43))
 
 
+# ---- sliding-window inference harness (tools/Tester.py) ---------------------------------------------
+from . import infer_oracle as IO  # noqa: E402
+
+
+@case("infer_image")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 3, 3, 40, 52), 90, 0.3) + 0.5}
+
+    def run(sd, inp):
+        return [IO.test_image(IO.fake_sr_model(), inp["x"], [16, 20], 6, 4), IO.test_image(IO.fake_sr_model(), inp["x"], [16, 20], 5, 4),
+                IO.test_image(IO.fake_sr_model(), inp["x"][..., :16, :20], [16, 20], 6, 4)]
+    return dict(inputs=inputs, run=run, no_weights=True)
+
+
+@case("infer_clips")
+def _():
+    def inputs():
+        return {"x": R.seeded((1, 11, 3, 24, 28), 91, 0.3) + 0.5}
+
+    def run(sd, inp):
+        return [IO.test_clips(IO.fake_sr_model(), inp["x"], 5, 2, [16, 16], 4, 4), IO.test_clips(IO.fake_sr_model(), inp["x"], 5, 3, None, None, 4),
+                IO.test_clips(IO.fake_sr_model(), inp["x"], 4, 0, [16, 16], 4, 4)]
+    return dict(inputs=inputs, run=run, no_weights=True)
+
+
+@case("infer_clips_max")
+def _():
+    def inputs():
+        x = R.seeded((1, 9, 3, 16, 16), 92, 0.3) + 0.5
+        return {"x": x, "hr": (0.5 * x.repeat_interleave(4, -2).repeat_interleave(4, -1) + 0.2 + R.seeded((1, 9, 3, 64, 64), 93, 0.05))}
+
+    def run(sd, inp):
+        out = IO.test_clips_max(IO.fake_sr_model(), inp["x"], inp["hr"], 4, 2, None, None, 4)
+        return [out, torch.from_numpy(IO.to_uint8(out).astype(np.float32))]
+    return dict(inputs=inputs, run=run, no_weights=True)
+
+
+@case("infer_vmg_clips")
+def _():
+    cfg = cfg_tiny_few(3)
+    chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+
+    def inputs():
+        return {"x": R.synthetic_clip(1, 5, 72, 64, 94)}
+
+    def run(sd, inp):
+        return [IO.test_clips(lambda clip: O.vmg_forward(sd, cfg, clip), inp["x"], 3, 1, [64, 64], 8, 4)]
+    return dict(inputs=inputs, run=run, chunk_of=chunk_of, window_of=window_of, cfg=cfg)
+
+
 # ---- fixture I/O -------------------------------------------------------------------------------------
 def save_fixture(path: str, shapes: Dict[str, List[int]], outs: List[torch.Tensor]):
     arrs = {"shapes": np.frombuffer(json.dumps(shapes).encode(), dtype=np.uint8)}

@@ -170,6 +170,36 @@ def reference_side(name, case, mods):
     if name == "loss":
         crit = Ls.CharbonnierLoss(eps=1e-12, if_aux_loss=True, aux_ratio=0.005)
         return {}, [crit(inp["x"], inp["y"]).reshape(1)]
+    if name.startswith("infer_"):
+        # tools/Tester.py's window loops, called as unbound methods on a stub `self` (Tester.__init__ builds a model from a
+        # checkpoint path and is not run); the third-party names its module imports come from oracle/_standins
+        import types
+        import tools.Tester as TT
+        from . import infer_oracle as IO
+
+        def tester(model, **kw):
+            return types.SimpleNamespace(model=model, scale=4, **kw)
+        x = inp["x"]
+        if name == "infer_image":
+            return {}, [TT.Tester.test_image(tester(IO.fake_sr_model(), test_spatial=[16, 20], overlapped_spatial_length=6), x),
+                        TT.Tester.test_image(tester(IO.fake_sr_model(), test_spatial=[16, 20], overlapped_spatial_length=5), x),
+                        TT.Tester.test_image(tester(IO.fake_sr_model(), test_spatial=[16, 20], overlapped_spatial_length=6), x[..., :16, :20])]
+        def clips(model, nf, of, sp, osl, fn="test_clips", **extra):
+            t = tester(model, test_num_frames=nf, overlapped_num_frames=of, test_spatial=sp, overlapped_spatial_length=osl)
+            t.test_image = types.MethodType(TT.Tester.test_image, t)
+            return getattr(TT.Tester, fn)(t, x, **extra)
+        if name == "infer_clips":
+            return {}, [clips(IO.fake_sr_model(), 5, 2, [16, 16], 4), clips(IO.fake_sr_model(), 5, 3, None, None),
+                        clips(IO.fake_sr_model(), 4, 0, [16, 16], 4)]
+        if name == "infer_clips_max":
+            out = clips(IO.fake_sr_model(), 4, 2, None, None, fn="test_clips_max", HR=inp["hr"])
+            import numpy as np
+            u8 = np.round(np.ascontiguousarray(out.cpu().squeeze().clamp(0, 1).numpy().squeeze().transpose(0, 2, 3, 1)) * 255.0).astype(np.uint8)  # Tester.py:249-250
+            return {}, [out, torch.from_numpy(u8.astype(np.float32))]
+        if name == "infer_vmg_clips":
+            m = _vmg_from_cfg(V, case["cfg"])
+            shapes = _load_recipe(m, case)
+            return shapes, [clips(m, 3, 1, [64, 64], 8)]
     if name.startswith("vmg_"):
         cfg = case["cfg"]
         m = _vmg_from_cfg(V, cfg)

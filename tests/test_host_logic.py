@@ -93,3 +93,17 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in vmg_hip.h but not exported"
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     assert hip.lib().vmg_version() >= 100
+
+
+def test_sliding_window_starts_match_oracle():
+    """vmg_amd.infer.tile_starts (host logic) == the oracle's restatement of tools/Tester.py:113-114 on every small case."""
+    from oracle import infer_oracle as IO
+    from vmg_amd import infer
+    for total in range(1, 70):
+        for size in (1, 4, 7, 16, 50):
+            for ov in range(0, size):
+                assert infer.tile_starts(total, size, ov) == IO.tile_starts(total, size, ov)
+    assert infer.tile_starts(100, 50, 25) == [0, 25, 50]          # cfg4: 100 frames -> windows at 0, 25, 50
+    assert infer.tile_starts(180, 128, 20) == [0, 52] and infer.tile_starts(320, 128, 20) == [0, 108, 192]
+    with pytest.raises(ValueError):
+        infer.tile_starts(10, 4, 4)

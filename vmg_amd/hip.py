@@ -62,6 +62,9 @@ SIGNATURES = {
     "vmg_ltam_bwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_float, c_void_p]),
+    "vmg_tile_accumulate": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p]),
+    "vmg_tile_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_conv_debug_stamps": (c_int, [c_void_p]),
     "vmg_prof_select_pixels": (c_int, [c_int64]),
     "vmg_prof_null_interval_us": (ctypes.c_double, [c_int, c_void_p]),
