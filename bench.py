@@ -96,11 +96,18 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the VMG hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: VMG_REHEARSE_ONE_GPU=1 puts every rank on device 0 and exchanges gradients over gloo (the
+    # driver's real runs use one GPU per rank and RCCL); it exercises the hooks / buckets / streams of the distributed step
+    rehearse = os.environ.get("VMG_REHEARSE_ONE_GPU") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from vmg_amd import hip
     from vmg_amd.data import synthetic_clip, synthetic_target
