@@ -66,7 +66,7 @@ struct ConvK {
   int halo_bytes;  // LDS bytes reserved for the halo tile
   int vec8;        // 1: out / res / aux / out_pre rows are 16-byte aligned with strides % 8 == 0, Cout % 16 == 0, no PixelShuffle
   unsigned long long* stamps;  // diagnostics: per-wave s_memrealtime stamps (8 per wave) when non-null (vmg_conv_debug_stamps)
-  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop, 64 no k rotation, 128 no XCD-aware tile order
+  int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop, 128 no XCD-aware tile order
 };
 
 template <typename T>
@@ -648,32 +648,57 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
     for (int i = 0; i < 4; ++i) rowoff[i] = ((wave + i) & 3) * rowb;
 
     Frag<T> wf[3][NTB], xf[3][4];
-    auto load_w = [&](int set, int k) {  // weights of k-step k (clamped: a padding step multiplies them by zeros)
+    // The wave walks k-steps k0, k0+1, ... with TWO cursors (weights run two steps ahead of the activations).  A cursor
+    // is advanced like an odometer -- (kx, ky, channel block) and a running byte offset into the packed weights -- because
+    // decoding a flat k index (divisions by 9 and 3, 64-bit products) for every load cost ~80 scalar instructions per
+    // k-step, more than everything else in the loop.  Past the last real k-step a cursor stays on it (`real` turns false).
+    struct Cur { int k, cbk, ky, kx; long long woff; };
+    auto cur_at = [&](int k) {
+      Cur c;
+      c.k = k;
       const int kc = min(k, nks - 1);
-      long long off;
       if (KS == 3) {
-        const int cbk = kc / 9, tap = kc - 9 * cbk, ky = tap / 3, kx = tap - 3 * ky;
-        off = (long long)(st0 + cbk * 3 + ky) * SS + kx * KSB;
+        c.cbk = kc / 9;
+        const int tap = kc - 9 * c.cbk;
+        c.ky = tap / 3;
+        c.kx = tap - 3 * c.ky;
+        c.woff = (long long)(st0 + c.cbk * 3 + c.ky) * SS + c.kx * KSB;
       } else {
-        off = (long long)(st0 + (kc >> 1)) * SS + (kc & 1) * KSB;
+        c.cbk = kc; c.ky = 0; c.kx = 0;
+        c.woff = (long long)(st0 + (kc >> 1)) * SS + (kc & 1) * KSB;
       }
-      const char* p = wlane + off;
+      return c;
+    };
+    auto advance = [&](Cur& c) {
+      ++c.k;
+      if (c.k < nks) {
+        if (KS == 3) {
+          c.woff += KSB;
+          if (++c.kx == 3) {
+            c.kx = 0;
+            c.woff += SS - 3 * KSB;
+            if (++c.ky == 3) { c.ky = 0; ++c.cbk; }
+          }
+        } else {
+          c.woff += (c.k & 1) ? KSB : SS - KSB;
+          c.cbk = c.k;
+        }
+      }
+    };
+    Cur cw = cur_at(k0), cx = cw;
+    auto load_w = [&](int set) {  // weights of the cursor's k-step (a padding step multiplies them by zeros)
+      const char* p = wlane + cw.woff;
 #pragma unroll
       for (int ct = 0; ct < NTB; ++ct) wf[set][ct].load(p + ct * 16 * CB);
+      advance(cw);
     };
-    auto load_x = [&](int set, int k) {
-      const bool real = k < nks;
-      const int kc = min(k, nks - 1);
-      int boff;
-      if (KS == 3) {
-        const int cbk = kc / 9, tap = kc - 9 * cbk, ky = tap / 3, kx = tap - 3 * ky;
-        boff = ky * rowb + kx * pixb + min(4 * cbk + g, CH - 1) * CB;
-      } else {
-        boff = min(4 * kc + g, CH - 1) * CB;
-      }
+    auto load_x = [&](int set) {
+      const bool real = cx.k < nks;
+      const int boff = (KS == 3 ? cx.ky * rowb + cx.kx * pixb : 0) + min(4 * cx.cbk + g, CH - 1) * CB;
       const char* base = real ? pixp + boff : zslot;
 #pragma unroll
       for (int i = 0; i < 4; ++i) xf[set][i].load(base + (real ? rowoff[i] : 0));
+      advance(cx);
     };
     auto mfma_set = [&](int set) {
 #pragma unroll
@@ -681,27 +706,19 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[ct][i] = mma(wf[set][ct], xf[set][i], acc[ct][i]);
     };
-    // Workgroups walk their k-range from different starting points (rotation by block index): at any instant the
-    // 500+ concurrent workgroups then ask L2 for different weight lines instead of all hammering the same channel.
-    const int rot = (a.dbg & 64) ? 0 : (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)per);
-    auto kmap = [&](int i) {  // i-th step of this wave -> k-step index (i >= per: a prefetch past the end, never used)
-      int r = i + rot;
-      r = r >= per ? r - per : r;
-      return k0 + min(r, per - 1);
-    };
     if (nks > 0) {
-      load_w(0, kmap(0));
-      load_w(1, kmap(1));
-      load_x(0, kmap(0));
+      load_w(0);
+      load_w(1);
+      load_x(0);
       for (int i = 0; i < per; i += 3) {
-        load_w(2, kmap(i + 2));
-        load_x(1, kmap(i + 1));
+        load_w(2);
+        load_x(1);
         mfma_set(0);
-        load_w(0, kmap(i + 3));
-        load_x(2, kmap(i + 2));
+        load_w(0);
+        load_x(2);
         mfma_set(1);
-        load_w(1, kmap(i + 4));
-        load_x(0, kmap(i + 3));
+        load_w(1);
+        load_x(0);
         mfma_set(2);
       }
     }
