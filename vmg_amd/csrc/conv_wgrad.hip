@@ -15,6 +15,8 @@
 // units through a wave-private LDS tile (no workgroup barriers in the main loop; next unit's global loads are in
 // flight while the current one is multiplied).  At the end the 4 waves' accumulators are summed with LDS float
 // atomics into a [co][ci][tap] image = the OIHW order, and written out with coalesced global float atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -540,6 +542,212 @@ __global__ __launch_bounds__(256) void conv_wgrad2_reduce_kernel(const float* __
 }
 
 // =====================================================================================================
+// v3 (bf16, 3x3): the v2 tile (144 co x 48 ci x 9 taps per workgroup) on EIGHT waves, two per SIMD.
+// v2's nine waves put three on one SIMD (its MFMA share bounds every unit) and leave 170 registers per wave, too few to
+// hold a second fragment set: LDS reads and MFMAs of a unit ran one after the other.  Here wave (h, q) owns co tiles
+// 5h..5h+4 (h = 1: four real tiles) x fragment columns 7q..7q+6 of the 27 (ci tile, tap) columns = 35 accumulator
+// tiles; with 256 registers the X fragment of the NEXT unit is read into the registers of the fragment just consumed,
+// so LDS reads run under the MFMAs.  Per unit the [dY tile | X tile] pair is one linear list of 1188 16-byte vectors
+// copied by LDS-DMA, three 1-KiB instructions per wave (lanes past the list or outside the image read a zero buffer):
+// the wait is COUNTED.  Three LDS buffers, one barrier per unit; slabs + ordered reduction as in v2.
+// =====================================================================================================
+constexpr int W3_WAVES = 8, W3_THREADS = 512, W3_SLOTS = 3;
+constexpr int W3_DYV = 576, W3_VECS = 576 + W2_XVEC;            // 1188 vectors per unit
+constexpr int W3_BUF = W3_SLOTS * W3_WAVES * 1024;               // 24576 B per buffer (every wave issues 3 full instructions)
+constexpr int W3_TILES = 36;                                     // 35 accumulator tiles + 1 bias tile per wave
+constexpr long long W3_WG_FLOATS = (long long)W3_WAVES * W3_TILES * 256;
+
+__device__ __forceinline__ bf16x8 tr_read(const char* p0, int rs) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + 4 * rs));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave >> 2, q = wave & 3;
+  const int ob = blockIdx.x * W2_DYC, ib = blockIdx.y * W2_XC;
+  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
+
+  f32x4 acc[5][7];
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  // ---- lane constants of the three copy instructions: vector L of the [dY | X] list
+  int s_off[W3_SLOTS], s_a[W3_SLOTS], s_b[W3_SLOTS], s_kind[W3_SLOTS];  // kind 0 dY (a = pixel), 1 X (a = row, b = column), 2 padding
+#pragma unroll
+  for (int sl = 0; sl < W3_SLOTS; ++sl) {
+    const int L = (sl * W3_WAVES + wave) * 64 + lane;
+    if (L < W3_DYV) {
+      const int pp = L / 18, v = L - pp * 18;
+      s_kind[sl] = (ob + v * 8 + 8 <= a.Cout) ? 0 : 2;
+      s_a[sl] = pp; s_b[sl] = 0;
+      s_off[sl] = (int)((pp * a.dy_ps + ob + v * 8) * 2);
+    } else if (L < W3_VECS) {
+      const int vec = L - W3_DYV, pp = vec / 6, v = vec - pp * 6;
+      const int rr = pp / W2_XW, col = pp - rr * W2_XW;
+      s_kind[sl] = (ib + v * 8 + 8 <= a.Cin) ? 1 : 2;
+      s_a[sl] = rr; s_b[sl] = col;
+      s_off[sl] = (int)((((long long)(rr - 1) * a.W + (col - 1)) * a.x_ps + ib + v * 8) * 2);
+    } else {
+      s_kind[sl] = 2; s_a[sl] = 0; s_b[sl] = 0; s_off[sl] = 0;
+    }
+  }
+  int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
+  {
+    const long long uu = u_lo - (long long)ipair * a.Upair;
+    iseg = (int)(uu % a.SEG);
+    const long long r = uu / a.SEG;
+    iy = (int)(r % a.H);
+    in_ = (int)(r / a.H);
+  }
+  auto issue = [&](int buf) {
+    const int x0 = iseg * 32;
+    const long long row = ((long long)in_ * a.H + iy) * a.W + x0;
+    const char* dyrow = a.dy[ipair] + row * a.dy_ps * 2;
+    const char* xrow = a.x[ipair] + row * a.x_ps * 2;
+    char* dst = smem + buf * W3_BUF;
+#pragma unroll
+    for (int sl = 0; sl < W3_SLOTS; ++sl) {
+      bool ok;
+      const char* src;
+      if (s_kind[sl] == 0) {
+        ok = x0 + s_a[sl] < a.W;
+        src = dyrow + s_off[sl];
+      } else {
+        const int yy = iy + s_a[sl] - 1, xx = x0 + s_b[sl] - 1;
+        ok = s_kind[sl] == 1 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        src = xrow + s_off[sl];
+      }
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ok ? src : zsrc), LDS_PTR(dst + (sl * W3_WAVES + wave) * 1024), 16, 0, 0);
+    }
+    if (++iseg == a.SEG) {
+      iseg = 0;
+      if (++iy == a.H) {
+        iy = 0;
+        if (++in_ == a.N) { in_ = 0; ++ipair; }
+      }
+    }
+  };
+
+  // ---- fragment addresses (within a buffer): dY rows are 288 B, X rows 96 B; lane i = 4qq+pp of a 16-lane group supplies
+  // block row qq, columns 4pp..4pp+3 of a transposed 4x16 block read
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_off = (8 * lg + (li >> 2)) * (W2_DYC * 2) + (h * 5 * 16 + 4 * (li & 3)) * 2;  // + c * 32 for co tile c of this wave
+  int b_off[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int col = min(q * 7 + j, 26), itile = col / 9, tap = col - 9 * itile, ky = tap / 3, kx = tap - 3 * ky;
+    b_off[j] = W3_DYV * 16 + ky * W2_XW * (W2_XC * 2) + (kx + 8 * lg + (li >> 2)) * (W2_XC * 2) + (itile * 16 + 4 * (li & 3)) * 2;
+  }
+
+  const long long nun = u_hi - u_lo;
+  if (nun > 0) issue(0);
+  if (nun > 1) issue(1);
+  if (nun > 2) issue(2);
+  if (nun > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (nun > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 af[5], bfg[7];
+  if (nun > 0) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) af[c] = tr_read(smem + a_off + c * 32, W2_DYC * 2);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) bfg[j] = tr_read(smem + b_off[j], W2_XC * 2);
+  }
+  int bn = 1;  // buffer of unit u+1
+  for (long long u = u_lo; u < u_hi; ++u) {
+    const bool has_next = u + 1 < u_hi;
+    if (u + 2 < u_hi) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u+1 landed; unit u+2 (3 instructions per wave) stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit u are complete
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int bu = bn == 0 ? 2 : bn - 1;  // buffer of unit u: free now
+    const char* src = smem + (has_next ? bn : bu) * W3_BUF;  // (last unit: re-read its own buffer; the values are not used)
+    bf16x8 an[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) an[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[j], acc[c][j], 0, 0, 0);
+      bfg[j] = tr_read(src + b_off[j], W2_XC * 2);
+    }
+    if (a.has_bias && q == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
+    }
+    if (u + 3 < u_hi) issue(bu);  // (after the MFMAs were handed to the matrix pipe: the copy's address arithmetic runs in their shadow)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) af[c] = an[c];
+    bn = bn == 2 ? 0 : bn + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
+  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W3_WAVES + wave) * (W3_TILES * 256);
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) *reinterpret_cast<f32x4*>(sl + ((c * 7 + j) * 64 + lane) * 4) = acc[c][j];
+  // bias tile: rows 4g..4g+3 of co tile c live in every column of D; column l15 < 5 of the slot carries co tile l15
+  if (a.has_bias && q == 0 && blockIdx.y == 0) {
+    f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (li < 5) pack = li == 0 ? accb[0] : (li == 1 ? accb[1] : (li == 2 ? accb[2] : (li == 3 ? accb[3] : accb[4])));
+    *reinterpret_cast<f32x4*>(sl + (35 * 64 + lane) * 4) = pack;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
+                                                                 float* __restrict__ dW, int I_total, int o0, int i0,
+                                                                 float* __restrict__ db, float scale) {
+  __shared__ float red[256];
+  const long long per_s = (long long)gy * gx * W3_WG_FLOATS;
+  for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
+    const long long i = e0 + (threadIdx.x & 63);
+    const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
+    if (threadIdx.x >= 64) continue;
+    const int r = (int)(i & 3);
+    const int lane = (int)((i >> 2) & 63);
+    long long qq = i >> 8;
+    const int tile = (int)(qq % W3_TILES);
+    qq /= W3_TILES;
+    const int wave = (int)(qq % W3_WAVES);
+    qq /= W3_WAVES;
+    const int coblk = (int)(qq % gx), ciblk = (int)(qq / gx);
+    const int h = wave >> 2, q = wave & 3;
+    const int g = lane >> 4, l15 = lane & 15;
+    if (tile < 35) {
+      const int c = tile / 7, j = tile - c * 7;
+      const int cot = h * 5 + c, col = q * 7 + j;
+      if (cot < 9 && col < 27) {
+        const int itile = col / 9, t = col - itile * 9;
+        const int co = coblk * W2_DYC + cot * 16 + 4 * g + r;
+        const int ci = ciblk * W2_XC + itile * 16 + l15;
+        if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 9 + t] += sum * scale;
+      }
+    } else if (db && q == 0 && ciblk == 0 && l15 < 5) {
+      const int cot = h * 5 + l15;
+      const int co = coblk * W2_DYC + cot * 16 + 4 * g + r;
+      if (cot < 9 && co < Cout) db[o0 + co] += sum * scale;
+    }
+  }
+}
+
+// =====================================================================================================
 // v2 for 1x1 convolutions / Linears (bf16): dW[co][ci] = sum_p dY[p][co] * X[p][ci], a GEMM whose K is the pixel list.
 // Workgroup = 9 waves (cg, it); output tile 144 co x 144 ci, wave (cg, it) owns co tiles 3cg..3cg+2 x ci tiles 3it..3it+2
 // (9 accumulator tiles + the bias tile for it == 0).  A unit = 32 consecutive pixels of the flat pixel list: both tiles
@@ -721,8 +929,24 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   if (S < 1) S = 1;
   const long long need = S * gx * gy * W2_WG_FLOATS * 4;
   if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
-  k.S = (int)S; k.slab = (float*)ws;
   hipStream_t st = (hipStream_t)stream;
+  static const bool use_v2 = getenv("VMG_WGRAD_V2") != nullptr;  // diagnostics: the nine-wave kernel
+  if (!use_v2 && S * gx * gy * W3_WG_FLOATS * 4 <= ws_bytes) {
+    k.S = (int)S; k.slab = (float*)ws;
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr3 = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 3 * W3_BUF, st, k);
+    VMG_LAUNCH_CHECK();
+    const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
+    const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
+    hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
+  k.S = (int)S; k.slab = (float*)ws;
   hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * W2_BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
