@@ -327,18 +327,17 @@ extern "C" int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void*
 }
 
 // =====================================================================================================
-// v2 (bf16, 3x3): large output tile, shared LDS tiles, slab reduction.
+// Large-tile kernels (bf16): shared LDS tiles, slab reduction.
 //
 // The v1 kernel above gives every workgroup a 48 x 16 x 9 output tile, so dY is re-read 9x and X 3x from L2/HBM (1.2 GB
 // for the batched gradient of one recurrent conv) and the float-atomic epilogue scales with the number of K splits.
-// v2: a workgroup of 9 waves owns ALL 144 output channels x 48 input channels x 9 taps; wave (cg, it) accumulates
-// co-tiles 3cg..3cg+2 x ci-tile it x 9 taps = 27 MFMA tiles.  Per 32-pixel K unit the dY tile [32][144] and the X
-// tile [3][34][48] are filled by LDS-DMA (global_load_lds, per-lane source, lane-linear destination; out-of-image
-// lanes read a zero buffer, so every wave issues the same 3 DMA instructions per unit and the wait can be COUNTED),
-// double-buffered, two barriers per unit.  dY is then read 3x, X once.  Partial results go to per-split slabs in the
-// accumulator's native layout with coalesced float4 stores; a second kernel sums the slabs in a fixed order (bitwise
-// reproducible, unlike atomics) and adds them into the OIHW gradient.  The bias gradient is one more MFMA per co-tile
-// against a ones operand.
+// Here a workgroup owns ALL 144 output channels x 48 input channels x 9 taps (3x3) or 144 x 144 (1x1).  Per 32-pixel K
+// unit the dY tile [32][144] and the X tile ([3][34][48] with its halo, or [32][144]) are filled by LDS-DMA
+// (global_load_lds, per-lane source, lane-linear destination; out-of-image lanes read a zero buffer, so every wave issues
+// the same number of DMA instructions per unit and the wait can be COUNTED) and read transposed.  Partial results go to
+// per-slab workspaces in the accumulator's native layout with coalesced float4 stores; a second kernel sums the slabs in
+// a fixed order (bitwise reproducible, unlike atomics) and adds them into the OIHW gradient.  The bias gradient is one
+// more MFMA per co tile against a ones operand.
 // =====================================================================================================
 namespace {
 
@@ -351,138 +350,14 @@ struct Wgrad2K {
   long long Upair, U;
   long long x_ps, dy_ps;
   int Cin, Cout;
-  float* slab;       // [S][ciblk][coblk][9 waves][28 tiles][64][4]
+  float* slab;       // [S][ciblk][coblk][8 waves][36 tiles][64][4]
   int N, H, W, SEG, S;
   int has_bias;
 };
 
-constexpr int W2_WAVES = 9, W2_THREADS = 576;
+constexpr int W2_WAVES = 9, W2_THREADS = 576;  // the 1x1 kernel's workgroup
 constexpr int W2_DYC = 144, W2_XC = 48, W2_XR = 3, W2_XW = 34;
-constexpr int W2_DY_BYTES = 32 * W2_DYC * 2;                // 9216
-constexpr int W2_X_BYTES = W2_XR * W2_XW * W2_XC * 2;       // 9792
-constexpr int W2_BUF = W2_DY_BYTES + W2_X_BYTES;            // 19008 (16-byte multiple)
 constexpr int W2_XVEC = W2_XR * W2_XW * (W2_XC / 8);        // 612 vectors in the X tile
-constexpr int W2_XVW = (W2_XVEC + W2_WAVES - 1) / W2_WAVES;  // 68 per wave -> 2 DMA instructions (64 + 4 lanes)
-constexpr int W2_TILES = 28;                                // 27 accumulator tiles + 1 bias tile per wave
-constexpr long long W2_WG_FLOATS = (long long)W2_WAVES * W2_TILES * 256;
-
-__global__ __launch_bounds__(W2_THREADS) void conv_wgrad2_kernel(const Wgrad2K a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = wave / 3, it = wave - cg * 3;
-  const int ob = blockIdx.x * W2_DYC, ib = blockIdx.y * W2_XC;
-  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
-  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
-
-  f32x4 acc[3][9];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 accb[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const bf16 one = (bf16)1.0f;
-  const bf16x8 ones = {one, one, one, one, one, one, one, one};
-
-  // Lane constants of the two tile copies: which vector of the tile a lane moves never changes, only the unit does.
-  const int p_dy = tid / 18, v_dy = tid - p_dy * 18;
-  const bool c_dy = ob + v_dy * 8 + 8 <= a.Cout;
-  const int off_dy = (int)((p_dy * a.dy_ps + ob + v_dy * 8) * 2);
-  int off_x[2], rr_x[2], col_x[2];
-  bool c_x[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int k = 64 * i + lane, vec = W2_XVW * wave + k;
-    const int pp = vec / 6, v = vec - pp * 6;
-    rr_x[i] = pp / W2_XW;
-    col_x[i] = pp - rr_x[i] * W2_XW;
-    c_x[i] = k < W2_XVW && vec < W2_XVEC && (ib + v * 8 + 8 <= a.Cin);
-    off_x[i] = (int)((((long long)(rr_x[i] - 1) * a.W + (col_x[i] - 1)) * a.x_ps + ib + v * 8) * 2);
-  }
-  const bool x_tail = W2_XVW * wave + 64 < W2_XVEC && W2_XVW > 64;  // (wave-uniform) the wave's second X instruction has lanes to move
-  // The unit to issue next, as (pair, image, row, 32-pixel segment): decoded once, then advanced like an odometer (all
-  // wave-uniform scalar work; the per-unit divisions of a flat index cost more than the MFMAs they fed).
-  int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
-  {
-    const long long uu = u_lo - (long long)ipair * a.Upair;
-    iseg = (int)(uu % a.SEG);
-    const long long r = uu / a.SEG;
-    iy = (int)(r % a.H);
-    in_ = (int)(r / a.H);
-  }
-  auto issue = [&](int buf) {
-    const int x0 = iseg * 32;
-    const long long row = ((long long)in_ * a.H + iy) * a.W + x0;  // first pixel of the unit
-    char* dyt = smem + buf * W2_BUF;
-    char* xt = dyt + W2_DY_BYTES;
-    {  // dY tile: 576 vectors, one per thread
-      const bool ok = c_dy && (x0 + p_dy < a.W);
-      const char* src = ok ? a.dy[ipair] + row * a.dy_ps * 2 + off_dy : zsrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dyt + wave * 1024), 16, 0, 0);
-    }
-    const char* xrow = a.x[ipair] + row * a.x_ps * 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // X tile: this wave's share of 68 vectors in two instructions (64 + 4 lanes)
-      if (i == 1 && !x_tail) break;
-      const int yy = iy + rr_x[i] - 1, xx = x0 + col_x[i] - 1;
-      const bool ok = c_x[i] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-      const char* src = ok ? xrow + off_x[i] : zsrc;
-      if (i == 0 || (64 + lane < W2_XVW && W2_XVW * wave + 64 + lane < W2_XVEC))
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(xt + (W2_XVW * wave + 64 * i) * 16), 16, 0, 0);
-    }
-    if (++iseg == a.SEG) {
-      iseg = 0;
-      if (++iy == a.H) {
-        iy = 0;
-        if (++in_ == a.N) { in_ = 0; ++ipair; }
-      }
-    }
-  };
-
-  // Three LDS buffers, ONE barrier per unit.  At the top of iteration u a wave waits for its own share of unit u (issued
-  // two iterations ago), then the barrier tells it that (a) every wave's share of unit u has landed and (b) every wave has
-  // finished reading unit u-1 (each drains its LDS reads before arriving) -- so unit u+2 may now overwrite u-1's buffer.
-  if (u_lo < u_hi) issue(0);
-  if (u_lo + 1 < u_hi) issue(1);
-  int buf = 0;
-  for (long long u = u_lo; u < u_hi; ++u) {
-    if (u + 1 < u_hi) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u landed; unit u+1 (3 instructions per wave) stays in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (u + 2 < u_hi) issue(buf == 0 ? 2 : buf - 1);
-    const char* dyt = smem + buf * W2_BUF;
-    const char* xt = dyt + W2_DY_BYTES;
-    bf16x8 af[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) af[c] = tr_frag(dyt, W2_DYC * 2, 0, (cg * 3 + c) * 16, lane);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int ky = t / 3, kx = t - 3 * ky;
-      const bf16x8 bfg = tr_frag(xt + ky * W2_XW * (W2_XC * 2), W2_XC * 2, kx, it * 16, lane);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg, acc[c][t], 0, 0, 0);
-    }
-    if (a.has_bias && it == 0 && blockIdx.y == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit u are complete before it arrives at the next barrier
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
-  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W2_WAVES + wave) * (W2_TILES * 256);
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(sl + ((c * 9 + t) * 64 + lane) * 4) = acc[c][t];
-  // bias tile: rows 4g..4g+3 of co-tile c live in lanes with (lane & 15) == 0; pack the three co-tiles into one tile slot
-  if (a.has_bias && it == 0 && blockIdx.y == 0) {
-    f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15;
-    if (l15 < 3) pack = l15 == 0 ? accb[0] : (l15 == 1 ? accb[1] : accb[2]);  // column l15 of D is as good as column 0
-    *reinterpret_cast<f32x4*>(sl + (27 * 64 + lane) * 4) = pack;
-  }
-}
 
 // Sum of element i over the S slabs, in a FIXED order (deterministic): the block's 4 waves each take the slabs
 // s = w, w+4, ... (coalesced 256-byte rows, 4 loads in flight), the 4 partial sums are combined through LDS as
@@ -508,43 +383,11 @@ __device__ __forceinline__ float slab_sum_4waves(const float* __restrict__ slab,
   return r;
 }
 
-// sums the S slabs in order and adds into dW / db
-__global__ __launch_bounds__(256) void conv_wgrad2_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
-                                                                 float* __restrict__ dW, int I_total, int o0, int i0,
-                                                                 float* __restrict__ db, float scale) {
-  __shared__ float red[256];
-  const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
-  for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {  // per_s is a multiple of 256
-    const long long i = e0 + (threadIdx.x & 63);
-    const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
-    if (threadIdx.x >= 64) continue;
-    // decode i -> (ciblk, coblk, wave, tile, lane, r)
-    const int r = (int)(i & 3);
-    const int lane = (int)((i >> 2) & 63);
-    long long q = i >> 8;
-    const int tile = (int)(q % W2_TILES);
-    q /= W2_TILES;
-    const int wave = (int)(q % W2_WAVES);
-    q /= W2_WAVES;
-    const int coblk = (int)(q % gx), ciblk = (int)(q / gx);
-    const int cg = wave / 3, it = wave - cg * 3;
-    const int g = lane >> 4, l15 = lane & 15;
-    if (tile < 27) {
-      const int c = tile / 9, t = tile - c * 9;
-      const int co = coblk * W2_DYC + (cg * 3 + c) * 16 + 4 * g + r;
-      const int ci = ciblk * W2_XC + it * 16 + l15;
-      if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 9 + t] += sum * scale;
-    } else if (db && it == 0 && ciblk == 0 && l15 < 3) {
-      const int co = coblk * W2_DYC + (cg * 3 + l15) * 16 + 4 * g + r;
-      if (co < Cout) db[o0 + co] += sum * scale;
-    }
-  }
-}
-
 // =====================================================================================================
-// v3 (bf16, 3x3): the v2 tile (144 co x 48 ci x 9 taps per workgroup) on EIGHT waves, two per SIMD.
-// v2's nine waves put three on one SIMD (its MFMA share bounds every unit) and leave 170 registers per wave, too few to
-// hold a second fragment set: LDS reads and MFMAs of a unit ran one after the other.  Here wave (h, q) owns co tiles
+// 3x3: the tile (144 co x 48 ci x 9 taps per workgroup) on EIGHT waves, two per SIMD.
+// (A nine-wave 3 x 3 layout of the same tile put three waves on one SIMD -- its MFMA share bounded every unit -- and left
+// 170 registers per wave, too few for a second fragment set: LDS reads and MFMAs ran one after the other; 161 us vs 124 us
+// for the 7-use gradient of a recurrent conv.)  Wave (h, q) owns co tiles
 // 5h..5h+4 (h = 1: four real tiles) x fragment columns 7q..7q+6 of the 27 (ci tile, tap) columns = 35 accumulator
 // tiles; with 256 registers the X fragment of the NEXT unit is read into the registers of the fragment just consumed,
 // so LDS reads run under the MFMAs.  Per unit the [dY tile | X tile] pair is one linear list of 1188 16-byte vectors
@@ -813,7 +656,6 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (u + 2 < u_hi) issue(buf == 0 ? 2 : buf - 1);
     const char* dyt = smem + buf * L2_BUF;
     const char* xt = dyt + L2_TILE_BYTES;
     bf16x8 af[3], bfg[3];
@@ -829,6 +671,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
 #pragma unroll
       for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
+    if (u + 2 < u_hi) issue(buf == 0 ? 2 : buf - 1);  // (behind the MFMAs: the copy's address arithmetic runs in their shadow)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     buf = buf == 2 ? 0 : buf + 1;
   }
@@ -878,7 +721,7 @@ __global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* 
 
 }  // namespace
 
-extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W2_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~83 MB)
+extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W3_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~94 MB)
 
 extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
                                          int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0,
@@ -927,31 +770,20 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   long long S = 256 / ((long long)gx * gy);
   if (S > k.U / 8) S = k.U / 8;
   if (S < 1) S = 1;
-  const long long need = S * gx * gy * W2_WG_FLOATS * 4;
+  const long long need = S * gx * gy * W3_WG_FLOATS * 4;
   if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
   hipStream_t st = (hipStream_t)stream;
-  static const bool use_v2 = getenv("VMG_WGRAD_V2") != nullptr;  // diagnostics: the nine-wave kernel
-  if (!use_v2 && S * gx * gy * W3_WG_FLOATS * 4 <= ws_bytes) {
-    k.S = (int)S; k.slab = (float*)ws;
-    static bool attr3 = false;
-    if (!attr3) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr3 = true;
-    }
-    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 3 * W3_BUF, st, k);
-    VMG_LAUNCH_CHECK();
-    const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
-    const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
-    hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
-    VMG_LAUNCH_CHECK();
-    return 0;
-  }
   k.S = (int)S; k.slab = (float*)ws;
-  hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * W2_BUF, st, k);
+  static bool attr3 = false;
+  if (!attr3) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr3 = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 3 * W3_BUF, st, k);
   VMG_LAUNCH_CHECK();
-  const long long per_s = (long long)gy * gx * W2_WG_FLOATS;
-  const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
-  hipLaunchKernelGGL(conv_wgrad2_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
+  const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
+  const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
+  hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }
