@@ -200,7 +200,7 @@ def test_conv_repeatable_under_load(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 12, 40, 144, 144, 3), (1, 9, 70, 64, 64, 2), (1, 16, 32, 288, 144, 1), (2, 8, 8, 144, 288, 4),
-                                   (1, 64, 64, 144, 144, 14)])
+                                   (1, 64, 64, 144, 144, 14), (2, 20, 36, 3, 144, 2)])
 def test_conv_wgrad_batched_large_tile(shape):
     """bf16 3x3 batched weight gradient = the large-tile kernel (LDS-DMA tiles, slabs + ordered reduction); the result
     must equal the sum over pairs of autograd gradients, accumulate into dW/db, and be bitwise reproducible."""
@@ -218,6 +218,8 @@ def test_conv_wgrad_batched_large_tile(shape):
         gb += g2
     init_w, init_b = R.seeded((Co, Ci, 3, 3), 80), R.seeded((Co,), 81)
     xd, dd = [x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys]
+    if Ci % 8:  # the stem conv: a 3-channel slice of the zero-padded 8-channel input (pixel stride 8)
+        xd = [F.pad(x, (0, 8 - Ci % 8))[..., :Ci] for x in xd]
     outs = []
     for rep in range(2):
         dW, db = init_w.clone().cuda(), init_b.clone().cuda()

@@ -754,15 +754,18 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
     }
   }
   // the large-tile path needs bf16, 3x3, 16-byte aligned 8-channel vectors; anything else takes the v1 kernel
+  // (a channel count that is not a multiple of 8 is fine when the pixel stride has room for the whole last vector -- the
+  // zero-padded input of the 3-channel stem conv, a slice of a wider tensor: the extra channels are computed and dropped)
+  const int cin8 = (Cin + 7) & ~7, cout8 = (Cout + 7) & ~7;
   bool ok = ws && dtype == VMG_BF16 && ks == 3 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
-            (Cin % 8 == 0) && (Cout % 8 == 0);
+            x_ps >= cin8 && dy_ps >= cout8;
   for (int p = 0; ok && p < npairs; ++p) ok = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
   if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
   VMG_CHECK(N > 0 && H > 0 && W > 0 && dW && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad arguments");
   Wgrad2K k;
   memset(&k, 0, sizeof(k));
   for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
-  k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout;
+  k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = cin8; k.Cout = cout8;  // bounds of the 8-channel vector loads; the reduce kernel keeps the true counts
   k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32);
   k.Upair = (long long)N * H * k.SEG; k.U = k.Upair * npairs;
   k.has_bias = db != nullptr;
