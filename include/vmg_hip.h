@@ -220,6 +220,12 @@ int vmg_tile_accumulate(int dtype, const void* patch, float* E, float* Wt, int64
                         int top, int bottom, int left, int right, void* stream);
 int vmg_tile_finalize(const float* E, const float* Wt, float* out_f32, unsigned char* out_u8, int64_t n, void* stream);
 
+/* ---- AdamW over a flat fp32 segment (reference: torch.optim.AdamW as set up in tools/Trainer.py:86-105) -----------------
+ * p, g, m, v: parameter, gradient, exp_avg, exp_avg_sq (n floats each, 16-byte aligned).  hyper (DEVICE memory, 4 floats):
+ * lr, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t).  torch's update order and formula, no amsgrad. */
+int vmg_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2, float eps,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

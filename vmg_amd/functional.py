@@ -34,12 +34,21 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
     return None, 1, 0
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Invalidates every cached weight pack: called by optimizers that rewrite parameter memory outside autograd's
+    version counters (train.FlatAdamW)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
            i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None) -> K.PackedConv:
     """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
     needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8)."""
     key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles)
-    ver = weight._version
+    ver = (weight._version, _WEIGHT_EPOCH[0])
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
         return hit[1]

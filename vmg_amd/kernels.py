@@ -84,15 +84,19 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
 
 def _pix_stride(t: torch.Tensor) -> int:
     """Pixel stride (elements) of a channels-last tensor whose leading dims are dense over pixels."""
-    if t.stride(-1) != 1:
+    st = t.stride()
+    if st[-1] != 1:
         raise HipError("channels must be the fastest dimension")
-    ps = t.stride(-2)
+    if t.is_contiguous():  # the common case: one call instead of a size/stride pair per dimension
+        return t.shape[-1]
+    sh = t.shape
+    ps = st[-2]
     # leading dims must be a dense pixel enumeration with that stride
     expect = ps
-    for d in range(t.dim() - 2, -1, -1):
-        if t.size(d) != 1 and t.stride(d) != expect:
-            raise HipError(f"tensor of shape {tuple(t.shape)} / strides {t.stride()} is not a dense pixel array")
-        expect *= t.size(d)
+    for d in range(len(sh) - 2, -1, -1):
+        if sh[d] != 1 and st[d] != expect:
+            raise HipError(f"tensor of shape {tuple(sh)} / strides {st} is not a dense pixel array")
+        expect *= sh[d]
     return ps
 
 

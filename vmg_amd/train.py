@@ -82,10 +82,14 @@ class GradBucketReducer:
     messages per link; the whole 104 MB gradient of few_levels is 2 buckets.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None, flat_grad: Optional[torch.Tensor] = None,
+                 offsets: Optional[List[int]] = None):
+        """flat_grad / offsets (FlatAdamW.g / .offsets, `params` in that order): the gradients already live in one flat
+        buffer, a bucket is a contiguous slice of it and is all-reduced IN PLACE -- no pack / unpack copies."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
+        self.flat_grad = flat_grad
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
         for p in reversed(self.params):
@@ -96,7 +100,15 @@ class GradBucketReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
+        if flat_grad is not None:
+            off_of = {id(p): o for p, o in zip(self.params, offsets)}
+            self.flat = []
+            for b in self.buckets:  # parameters of a bucket are neighbours in the flat buffer (reverse order): one slice
+                lo = min(off_of[id(p)] for p in b)
+                hi = max(off_of[id(p)] + (p.numel() + 3) // 4 * 4 for p in b)
+                self.flat.append(flat_grad[lo:min(hi, flat_grad.numel())])
+        else:
+            self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
         self.bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
@@ -130,7 +142,8 @@ class GradBucketReducer:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
+            if self.flat_grad is None:
+                torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.works.append((bi, work))
 
@@ -158,7 +171,8 @@ class GradBucketReducer:
                 if self.side is not None:
                     torch.cuda.current_stream().wait_stream(self.side)
                 flat.div_(self.world)
-                torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(flat.split([p.numel() for p in b])))
+                if self.flat_grad is None:
+                    torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(flat.split([p.numel() for p in b])))
         self.reset()
 
 
@@ -168,6 +182,114 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src, group=group)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizer: AdamW over one flat buffer
+# ---------------------------------------------------------------------------------------------------------
+class FlatAdamW:
+    """torch.optim.AdamW's update (tools/Trainer.py:86-105 builds the reference's optimizer) over ONE flat fp32 buffer.
+
+    All parameters are re-homed as views of `self.p` (group-major, registration order inside a group), their gradients
+    are persistent views of `self.g`, the moments live in `self.m` / `self.v`.  A step is one HIP kernel per parameter
+    group (vmg_adamw_flat: 28 bytes per parameter, HBM-bound) instead of ~26 multi-tensor launches over 560 tensors, and
+    the data-parallel exchange all-reduces slices of `self.g` in place (no pack / unpack copies).  The per-step scalars
+    travel through a small device tensor, so the step can be captured in a hipGraph.  GPU only (no CPU path)."""
+
+    def __init__(self, groups, lr: float = 2e-4, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.0):
+        from . import hip
+        self.groups = []
+        params = []
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            self.groups.append({"params": ps, "lr": float(g.get("lr", lr)), "weight_decay": float(g.get("weight_decay", weight_decay)), "initial_lr": float(g.get("lr", lr))})
+            params += ps
+        if not params:
+            raise ValueError("FlatAdamW: no parameters")
+        dev = params[0].device
+        hip.require_cuda(*params)
+        if any(p.dtype != torch.float32 for p in params):
+            raise hip.HipError("FlatAdamW keeps fp32 master parameters")
+        self.betas, self.eps, self.t = (float(betas[0]), float(betas[1])), float(eps), 0
+        # every tensor starts on a 16-byte boundary of the flat buffers (4 floats)
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.n = total
+        self.p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.params, self.offsets = params, offs
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.p[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.g[o:o + p.numel()].view_as(p)
+        # group segments [start, end) in the flat buffer
+        k = 0
+        for g in self.groups:
+            n = len(g["params"])
+            g["start"] = offs[k] if n else total
+            g["end"] = (offs[k + n] if k + n < len(offs) else total) if n else total
+            k += n
+        self.hyper = torch.zeros(len(self.groups), 4, dtype=torch.float32, device=dev)
+        # pinned staging ring: the upload is asynchronous, so a row is not rewritten until 64 steps later
+        self._ring = torch.zeros(64, len(self.groups), 4, dtype=torch.float32).pin_memory()
+
+    @property
+    def param_groups(self):
+        return self.groups
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are persistent views of the flat buffer: one memset (set_to_none is accepted and ignored)."""
+        self.g.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:  # someone replaced the view: re-attach
+                p.grad = self.g[o:o + p.numel()].view_as(p)
+
+    def _upload(self):
+        b1, b2 = self.betas
+        host = self._ring[self.t % 64]
+        for i, g in enumerate(self.groups):
+            host[i, 0] = g["lr"]
+            host[i, 1] = g["weight_decay"]
+            host[i, 2] = 1.0 - b1 ** self.t
+            host[i, 3] = math.sqrt(1.0 - b2 ** self.t)
+        self.hyper.copy_(host, non_blocking=True)
+
+    def advance(self):
+        """Host side of a step: bump the step count and send this step's scalars (call before replaying a captured graph)."""
+        self.t += 1
+        self._upload()
+
+    def launch(self):
+        from . import hip
+        lib = hip.lib()
+        for i, g in enumerate(self.groups):
+            n = g["end"] - g["start"]
+            if n <= 0:
+                continue
+            o = 4 * g["start"]
+            hip.check(lib.vmg_adamw_flat(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, n,
+                                         self.hyper.data_ptr() + 16 * i, self.betas[0], self.betas[1], self.eps, hip.stream_ptr()), "vmg_adamw_flat")
+
+    @torch.no_grad()
+    def step(self):
+        self.advance()
+        self.launch()
+
+    def state_dict(self):
+        return {"t": self.t, "m": self.m, "v": self.v, "groups": [{k: g[k] for k in ("lr", "weight_decay", "initial_lr")} for g in self.groups]}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        for g, s in zip(self.groups, sd["groups"]):
+            g.update(s)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -189,11 +311,15 @@ class TrainStep:
             groups[1]["params"] = [p for p in rest if id(p) not in wd_ids]
             groups.append({"params": [p for p in rest if id(p) in wd_ids], "weight_decay": weight_decay})
         on_gpu = next(model.parameters()).is_cuda
-        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0, fused=on_gpu, capturable=on_gpu)
+        if on_gpu:
+            self.opt = FlatAdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
+            self.reducer = GradBucketReducer(self.opt.params, bucket_bytes, flat_grad=self.opt.g, offsets=self.opt.offsets) if distributed else None
+        else:  # host-side rehearsals only (the model itself has no CPU path)
+            self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
+            self.reducer = GradBucketReducer(model.parameters(), bucket_bytes) if distributed else None
         self.graph = None
         self._static = None
         self.loss_args = dict(eps=eps_loss, aux=aux, aux_ratio=aux_ratio)
-        self.reducer = GradBucketReducer(model.parameters(), bucket_bytes) if distributed else None
         if distributed:
             broadcast_module_state(model)
 
@@ -229,6 +355,8 @@ class TrainStep:
         if lrs is not None:
             self._static[0].copy_(lrs)
             self._static[1].copy_(hrs)
+        if isinstance(self.opt, FlatAdamW):
+            self.opt.advance()
         self.graph.replay()
         return self._loss
 
@@ -244,6 +372,13 @@ class TrainStep:
         self._flush()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
+        if isinstance(self.opt, FlatAdamW):
+            if self.graph is None and not torch.cuda.is_current_stream_capturing():
+                self.opt.advance()  # host scalars of this step (a captured graph gets them from replay())
+            self.opt.launch()
+            from . import functional as FH
+            FH.bump_weight_epoch()  # the kernel rewrote the parameters behind autograd's version counters
+        else:
+            self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         return loss.detach()
