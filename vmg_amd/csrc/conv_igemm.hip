@@ -142,21 +142,20 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
         int r = (int)(((float)L0 + 0.5f) * (1.0f / (float)row_vecs));  // exact: L0 < 2^16, row_vecs <= 720
         int rem = L0 - r * row_vecs;
         const int dr = 256 / row_vecs, drem = 256 - dr * row_vecs;
+        // tile origin as a wave-uniform 64-bit pointer (may lie before the tensor for border tiles: only in-image lanes use
+        // it); per lane a 32-bit offset -- (r*W + p)*ps_b + 16v stays far below 2^31 for r <= THH, W <= 8192
+        const int y0 = (KS == 3) ? ty * TH - 1 : 0, x0 = (KS == 3) ? tx * 16 - 1 : 0;
+        const char* origin = (KS == 3) ? sp + (((long long)n * a.H + y0) * a.W + x0) * ps_b : sp + m0 * ps_b;
+        const int ps32 = (int)ps_b, rowstep = ((KS == 3) ? a.W : 16) * ps32;
+        const long long mleft = a.M - m0;  // KS == 1: pixels from the tile start to the end of the matrix
         for (int i0 = wave * 64; i0 < total; i0 += 256) {
           const int p = (int)(((float)rem + 0.5f) * inv_vpp);  // exact for these ranges (rem < 2^16, vpp <= 40)
           const int v = rem - p * vpp;
           bool ok = r < THH;
-          long long goff;
-          if (KS == 3) {
-            const int y = ty * TH + r - 1, x = tx * 16 - 1 + p;
-            ok = ok && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            goff = (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16;
-          } else {
-            const long long m = m0 + r * 16 + p;
-            ok = ok && m < a.M;
-            goff = m * ps_b + v * 16;
-          }
-          const char* gp = ok ? sp + goff : reinterpret_cast<const char*>(&g_conv_zero16);
+          if (KS == 3) ok = ok && (unsigned)(y0 + r) < (unsigned)a.H && (unsigned)(x0 + p) < (unsigned)a.W;
+          else ok = ok && (long long)(r * 16 + p) < mleft;
+          const int off = r * rowstep + p * ps32 + v * 16;
+          const char* gp = ok ? origin + off : reinterpret_cast<const char*>(&g_conv_zero16);
           __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(halo + i0 * 16), 16, 0, 0);
           rem += drem;
           r += dr;
