@@ -675,8 +675,12 @@ class VMG(nn.Module):
             xi = F.adaptive_avg_pool2d(lrs.reshape(B * T, C, H, W), (h, w)).reshape(B, T, C, h, w)
             a = xi[:, :-1].reshape(-1, C, h, w)
             b = xi[:, 1:].reshape(-1, C, h, w)
-            ff = self.spynet(b, a).view(B, T - 1, 2, h, w)
-            fb = ff.flip(1) if self.frames_mirror else self.spynet(a, b).view(B, T - 1, 2, h, w)
+            if self.frames_mirror:
+                ff = self.spynet(b, a).view(B, T - 1, 2, h, w)
+                fb = ff.flip(1)
+            else:  # both directions in ONE SPyNet pass (twice the batch, half the launches; per-sample results unchanged)
+                both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0))
+                ff, fb = both[:a.shape[0]].view(B, T - 1, 2, h, w), both[a.shape[0]:].view(B, T - 1, 2, h, w)
             fwd.append(ff)
             bwd.append(fb)
         return fwd, bwd
