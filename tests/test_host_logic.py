@@ -107,3 +107,22 @@ def test_sliding_window_starts_match_oracle():
     assert infer.tile_starts(180, 128, 20) == [0, 52] and infer.tile_starts(320, 128, 20) == [0, 108, 192]
     with pytest.raises(ValueError):
         infer.tile_starts(10, 4, 4)
+
+
+def test_train_loss_matches_reference_fixture_and_oracle_gradient():
+    """vmg_amd.train.charbonnier_edge_loss (one Laplacian pyramid of x - y, by linearity) against the number the reference's
+    CharbonnierLoss produced (tests/golden/loss.npz) and against the oracle's gradient (which builds both pyramids)."""
+    import os
+    import numpy as np
+    from oracle import cases as C
+    from oracle import vmg_oracle as O
+    from vmg_amd.train import charbonnier_edge_loss
+    inp = C.CASES["loss"]["inputs"]()
+    _, ref = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+    x = inp["x"].clone().requires_grad_(True)
+    got = charbonnier_edge_loss(x, inp["y"])
+    assert abs(float(got) - float(ref[0]["sub"][0])) <= 1e-6 * max(1.0, abs(float(ref[0]["sub"][0])))
+    got.backward()
+    xo = inp["x"].clone().requires_grad_(True)
+    O.charbonnier_edge_loss(xo, inp["y"]).backward()
+    assert float((x.grad - xo.grad).abs().max()) <= 1e-6 * max(1e-3, float(xo.grad.abs().max()))
