@@ -65,3 +65,33 @@ def test_reweight_mix_and_gate_fwd_bwd(dtype):
     assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
     for i, (g1, g2) in enumerate(zip(gg, wg)):
         assert float((g1.float().cpu() - g2).abs().max()) <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(g2.abs().max())), i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_drop_path(dtype):
+    """res + DropPath(y) * s in one kernel: timm semantics (per-sample mask of 0 or 1/keep), eval / p = 0 is a plain add, and the
+    gradients are dy (residual) and dy * mask * s (branch)."""
+    from vmg_amd import functional as FH
+    torch.manual_seed(0)
+    B, T, H, W, C = 6, 2, 8, 8, 144
+    res = torch.randn(B, T, H, W, C, device="cuda").to(dtype).requires_grad_(True)
+    y = torch.randn(B, T, H, W, C, device="cuda").to(dtype).requires_grad_(True)
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    out = FH.residual_drop_path(res, y, 0.0, True, 1.0)
+    assert float((out.float() - (res.float() + y.float())).abs().max()) <= tol
+    out = FH.residual_drop_path(res, y, 0.3, False, 0.5)
+    assert float((out.float() - (res.float() + 0.5 * y.float())).abs().max()) <= tol
+    p, s = 0.4, 0.5
+    out = FH.residual_drop_path(res, y, p, True, s)
+    ratio = ((out.float() - res.float()) / y.float()).detach()
+    seen = set()
+    for b in range(B):
+        r = float(ratio[b].median())
+        assert abs(r) <= tol or abs(r - s / (1 - p)) <= 5 * tol + 1e-3, r
+        assert float((ratio[b] - r).abs().median()) <= 5 * tol + 1e-3
+        seen.add(round(r, 2))
+    dy = torch.randn_like(out)
+    out.backward(dy)
+    assert torch.equal(res.grad, dy)
+    m = ratio.reshape(B, -1).median(1).values.reshape(B, 1, 1, 1, 1)
+    assert float((y.grad.float() - dy.float() * m).abs().max()) <= 5 * tol * max(1.0, float(dy.abs().max())) + 1e-3

@@ -439,6 +439,40 @@ class _ChannelAttention(torch.autograd.Function):
 def channel_attention_residual(r, x, w1, b1, w2, b2, out_scale: float):
     return _ChannelAttention.apply(r, x, w1, b1, w2, b2, float(out_scale))
 
+class _ResidualDropPath(torch.autograd.Function):
+    """res + y * g with g a per-(sample, channel) fp32 coefficient: the TAB residuals `x + DropPath(y) * s`
+    (models/function.py:1212-1217) in ONE pass (HIP, the channel-attention scale kernel) instead of mask-multiply, scale and
+    add; the backward is one multiply (d_res is dy itself)."""
+
+    @staticmethod
+    def forward(ctx, res, y, g):
+        out = K.tab_elementwise(K.OP_CA_FWD, y.contiguous(), res.contiguous(), coef=g, s=1.0, G=g.shape[0])
+        ctx.save_for_backward(g)
+        ctx.bshape = (g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (g,) = ctx.saved_tensors
+        return dy, dy * g.reshape(ctx.bshape).to(dy.dtype), None
+
+
+def residual_drop_path(res: torch.Tensor, y: torch.Tensor, p: float, training: bool, scale: float = 1.0) -> torch.Tensor:
+    """res + DropPath_p(y) * scale with timm's DropPath semantics (per-sample Bernoulli(1-p) mask / (1-p), sample = dim 0)."""
+    if (p == 0.0 or not training) and scale == 1.0:
+        return res + y
+    B, C = y.shape[0], y.shape[-1]
+    if p > 0.0 and training:
+        keep = 1.0 - p
+        mask = torch.empty(B, 1, dtype=torch.float32, device=y.device).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        g = (mask * scale).expand(B, C).contiguous()
+    else:
+        g = torch.full((B, C), float(scale), dtype=torch.float32, device=y.device)
+    return _ResidualDropPath.apply(res, y, g)
+
+
 
 class _ReweightMix(torch.autograd.Function):
     """Softmax re-weighting of the three mixer branches (models/function.py:791-793):

@@ -33,17 +33,6 @@ from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, HipError
 # ---------------------------------------------------------------------------------------------------------
 # small helpers
 # ---------------------------------------------------------------------------------------------------------
-def _drop_path(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
-    """timm DropPath semantics: per-sample Bernoulli(1-p) mask scaled by 1/(1-p) (models/function.py:1210)."""
-    if p == 0.0 or not training:
-        return x
-    keep = 1.0 - p
-    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-    if keep > 0.0:
-        mask.div_(keep)
-    return x * mask
-
-
 def conv(mod: nn.Conv2d, srcs: Sequence[torch.Tensor], N: int, H: int, W: int, **kw) -> torch.Tensor:
     return FH.conv2d(srcs, mod.weight, mod.bias, N, H, W, ks=mod.kernel_size[0], **kw)
 
@@ -277,11 +266,11 @@ class TAB(nn.Module):
         s = self.spatial_scale
         dp = self.drop_prob > 0.0 and self.training
         y = self.spatial_mixing(lnorm(self.norm2, x))
-        x = x + (_drop_path(y, self.drop_prob, self.training) * s if (dp or s != 1.0) else y)
+        x = FH.residual_drop_path(x, y, self.drop_prob, self.training, s)  # one pass: mask, scale and add
         n3 = lnorm(self.norm3, x)
         if isinstance(self.channel_mixing, Mlp_cnn) and not dp and s == 1.0:
             return self.channel_mixing(n3, res=x)  # residual fused in the Linear epilogue
-        return x + _drop_path(self.channel_mixing(n3), self.drop_prob, self.training) * s
+        return FH.residual_drop_path(x, self.channel_mixing(n3), self.drop_prob, self.training, s)
 
 
 # ---------------------------------------------------------------------------------------------------------
