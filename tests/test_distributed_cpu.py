@@ -33,7 +33,7 @@ class _Net(torch.nn.Module):
         return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, flat=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,7 +42,20 @@ def _worker(rank, world, port, q):
     net = _Net()
     net.gamma.fill_(float(rank + 5))
     broadcast_module_state(net)
-    red = GradBucketReducer(net.parameters(), bucket_bytes=512)  # several small buckets
+    if flat:
+        # the layout train.FlatAdamW gives the gradients: persistent views of one flat buffer, every tensor on a 4-float
+        # boundary; buckets are slices of it, all-reduced in place
+        params = list(net.parameters())
+        offs, total = [], 0
+        for p_ in params:
+            offs.append(total)
+            total += (p_.numel() + 3) // 4 * 4
+        gflat = torch.zeros(total)
+        for p_, o in zip(params, offs):
+            p_.grad = gflat[o:o + p_.numel()].view_as(p_)
+        red = GradBucketReducer(params, bucket_bytes=512, flat_grad=gflat, offsets=offs)
+    else:
+        red = GradBucketReducer(net.parameters(), bucket_bytes=512)  # several small buckets
     outs = []
     for step in range(2):
         torch.manual_seed(7 + 10 * step + rank)
@@ -50,18 +63,23 @@ def _worker(rank, world, port, q):
         net(x).square().mean().backward()
         red.finish()
         outs.append({n: (p.grad.numpy().copy() if p.grad is not None else None) for n, p in net.named_parameters()})
-        net.zero_grad(set_to_none=True)
+        if flat:
+            assert all(p_.grad.data_ptr() == gflat.data_ptr() + 4 * o for p_, o in zip(params, offs))  # still the views
+            gflat.zero_()
+        else:
+            net.zero_grad(set_to_none=True)
     # plain numpy through the queue (tensor fd-sharing breaks once the producer exits)
     q.put((rank, {n: p.detach().numpy().copy() for n, p in net.named_parameters()}, net.gamma.numpy().copy(), outs, len(red.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_matches_manual_average():
+@pytest.mark.parametrize("flat", [False, True])
+def test_bucketed_allreduce_matches_manual_average(flat):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, flat)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
