@@ -1,7 +1,13 @@
 // Stride-1 "same" convolution (KS = 3 or 1; KS = 1 is every Linear on the path) as an MFMA implicit GEMM
 // for gfx950, channels-last activations, with a fused epilogue.  See include/vmg_hip.h for the contract.
 //
-// Decomposition (one workgroup = 4 waves = 256 threads):
+// Two kernels share the packed-weight layout, the halo copy (stage_halo) and the epilogues:
+//   * conv_igemm_kernel  -- the four waves split the PIXELS of the tile; weights stream through an LDS ring.  Every shape,
+//     bf16 and fp32 (the parity mode); described right below.
+//   * conv_ksplit_kernel -- the four waves split the K LOOP, weights go global -> register; bf16, <= 5 cout tiles per
+//     workgroup: the 144- / 288-channel 3x3 convs that dominate the path.  Described at its definition.
+//
+// conv_igemm_kernel (one workgroup = 4 waves = 256 threads):
 //   * spatial tile of TH = 4*MT rows x 16 columns (KS = 3) or 64*MT consecutive rows of the (M, C) matrix
 //     (KS = 1); wave w owns MT 16-pixel rows of it; blockIdx.y selects a block of NTB*16 output channels.
 //   * K order = for each source tensor (a channel block of <= 160 channels; virtual concat = several sources):
@@ -11,8 +17,9 @@
 //       per-lane (tap, chunk) bookkeeping of a (tap, chunk)-ordered K cost as much as the MFMAs it fed).
 //   * a STAGE = one (cbk, ky) row of 3 taps (3x3) or 2 channel blocks (1x1): a fully unrolled block in which the LDS
 //     fragment reads of k-step j+1 are issued before the MFMAs of k-step j (two static register sets).
-//   * the source's halo tile ((TH+2) x 18 pixels, all channels of the block) is staged once in LDS by LDS-DMA rows;
-//     the activation operand of every k-step is a plain 16-byte LDS read at (pixel + tap offset).
+//   * the source's halo tile ((TH+2) x 18 pixels, all channels of the block) is staged once in LDS as one linear array of
+//     16-byte vectors copied by LDS-DMA; the activation operand of every k-step is a plain 16-byte LDS read at
+//     (pixel + tap offset).
 //   * packed weights stream through an LDS ring of stages filled by global_load_lds (16 B/lane, 1 KiB per
 //     instruction).  Stage images are padded to a multiple of 4 KiB so every wave issues the same number IPW of
 //     instructions and "stage s has landed" is a COUNTED s_waitcnt vmcnt((RING-2)*IPW): with 3 slots the younger
