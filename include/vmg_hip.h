@@ -226,6 +226,17 @@ int vmg_tile_finalize(const float* E, const float* Wt, float* out_f32, unsigned 
 int vmg_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2, float eps,
                    void* stream);
 
+/* ---- Charbonnier + edge loss (reference: utils/loss.py:22-79, CharbonnierLoss(eps, if_aux_loss=True, aux_ratio)) ---------
+ * x, y: (planes, H, W) fp32 images, planes = B*T*3.  fwd: a1 (planes, ceil(H/2), ceil(W/2)) scratch, ld (planes, H, W) = the
+ * Laplacian of x - y (kept for the backward), partial: 2 floats per block (vmg_charbonnier_edge_blocks of them): sums of
+ * sqrt(d^2 + eps) and sqrt(ld^2 + eps); loss = (sum0 + aux_ratio * sum1) / (planes*H*W).
+ * bwd: dx = gs1 * d / sqrt(d^2 + eps) + gs2 * lap^T(ld / sqrt(ld^2 + eps));  gs1 = dL / n, gs2 = dL * aux_ratio / n. */
+int vmg_charbonnier_edge_blocks(int64_t planes, int H, int W);
+int vmg_charbonnier_edge_fwd(const float* x, const float* y, float* a1, float* ld, float* partial, int64_t planes, int H, int W, float eps,
+                             void* stream);
+int vmg_charbonnier_edge_bwd(const float* x, const float* y, const float* ld, float* u, float* dx, int64_t planes, int H, int W, float eps,
+                             float gs1, float gs2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,30 @@ def test_train_step_uses_flat_buffers_and_repacks_weights():
     m.train()
     l2 = float(ts(x, y))
     assert l1 == l1 and l2 == l2
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 3, 32, 32), (2, 3, 3, 65, 47), (1, 1, 3, 256, 256), (1, 1, 3, 5, 3)])
+def test_charbonnier_edge_loss_kernels(shape):
+    """csrc/loss.hip (Laplacian pyramid of x - y with replicate padding and its adjoint) against the oracle's loss -- pinned
+    by the reference's CharbonnierLoss fixture -- in value and gradient, odd sizes and the fixture's own inputs."""
+    import os
+    import numpy as np
+    from oracle import cases as C
+    from oracle import recipe as R
+    from oracle import vmg_oracle as O
+    from vmg_amd.train import charbonnier_edge_loss_hip
+    x, y = R.seeded(shape, 301, 0.3) + 0.5, R.seeded(shape, 302, 0.3) + 0.5
+    xo = x.clone().requires_grad_(True)
+    lo = O.charbonnier_edge_loss(xo, y)
+    lo.backward()
+    xg = x.cuda().requires_grad_(True)
+    lg = charbonnier_edge_loss_hip(xg, y.cuda())
+    lg.backward()
+    assert abs(float(lg) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+    gmax = float(xo.grad.abs().max())
+    assert float((xg.grad.cpu() - xo.grad).abs().max()) <= 2e-5 * gmax + 1e-12
+    if shape == (1, 2, 3, 32, 32):  # the reference fixture's case
+        inp = C.CASES["loss"]["inputs"]()
+        _, ref = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+        got = charbonnier_edge_loss_hip(inp["x"].cuda(), inp["y"].cuda())
+        assert abs(float(got) - float(ref[0]["sub"][0])) <= 2e-6 * max(1.0, abs(float(ref[0]["sub"][0])))

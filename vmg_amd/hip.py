@@ -62,6 +62,9 @@ SIGNATURES = {
     "vmg_ltam_bwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_float, c_void_p]),
+    "vmg_charbonnier_edge_blocks": (c_int, [c_int64, c_int, c_int]),
+    "vmg_charbonnier_edge_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "vmg_charbonnier_edge_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "vmg_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_void_p]),
     "vmg_tile_accumulate": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p]),

@@ -54,6 +54,49 @@ def charbonnier_edge_loss(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-12, 
     return loss + aux_ratio * torch.mean(torch.sqrt(ld ** 2 + eps))
 
 
+class _CharbonnierEdgeHip(torch.autograd.Function):
+    """The same loss on the HIP kernels of csrc/loss.hip (four HBM-bound gathers instead of ~40 torch / MIOpen launches):
+    forward keeps the Laplacian of x - y, backward applies the adjoint pyramid.  x: (B,T,3,H,W) fp32 on the GPU."""
+
+    @staticmethod
+    def forward(ctx, x, y, eps, aux_ratio):
+        from . import hip
+        hip.require_cuda(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        if x.dtype != torch.float32 or y.dtype != torch.float32 or x.shape != y.shape:
+            raise hip.HipError("charbonnier_edge_loss: fp32 tensors of one shape expected")
+        H, W = x.shape[-2:]
+        planes = x.numel() // (H * W)
+        lib = hip.lib()
+        nb = int(lib.vmg_charbonnier_edge_blocks(planes, H, W))
+        a1 = torch.empty(planes, (H + 1) // 2, (W + 1) // 2, dtype=torch.float32, device=x.device)
+        ld = torch.empty_like(x)
+        partial = torch.empty(nb, 2, dtype=torch.float32, device=x.device)
+        hip.check(lib.vmg_charbonnier_edge_fwd(x.data_ptr(), y.data_ptr(), a1.data_ptr(), ld.data_ptr(), partial.data_ptr(), planes, H, W,
+                                               float(eps), hip.stream_ptr()), "vmg_charbonnier_edge_fwd")
+        sums = partial.double().sum(0)  # fixed-order reduction of the per-block partials: reproducible
+        n = x.numel()
+        ctx.save_for_backward(x, y, ld, a1)
+        ctx.args = (float(eps), float(aux_ratio), n, planes, H, W)
+        return ((sums[0] + aux_ratio * sums[1]) / n).float()
+
+    @staticmethod
+    def backward(ctx, dl):
+        from . import hip
+        x, y, ld, a1 = ctx.saved_tensors
+        eps, aux_ratio, n, planes, H, W = ctx.args
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().vmg_charbonnier_edge_bwd(x.data_ptr(), y.data_ptr(), ld.data_ptr(), a1.data_ptr(), dx.data_ptr(), planes, H, W, eps,
+                                                     1.0 / n, aux_ratio / n, hip.stream_ptr()), "vmg_charbonnier_edge_bwd")
+        # the incoming gradient is a device scalar (1 when the loss is the root): applied on the device, never read on the host
+        return dx.mul_(dl), None, None, None
+
+
+def charbonnier_edge_loss_hip(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-12, aux_ratio: float = 0.005) -> torch.Tensor:
+    """charbonnier_edge_loss(x, y, aux=True) on the GPU kernels (utils/loss.py:22-79)."""
+    return _CharbonnierEdgeHip.apply(x, y, eps, aux_ratio)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # LR schedule (utils/lr_scheduler.py:5-33)
 # ---------------------------------------------------------------------------------------------------------
@@ -369,7 +412,10 @@ class TrainStep:
 
     def _eager(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
         out = self.model(lrs)
-        loss = charbonnier_edge_loss(out.float(), hrs.float(), **self.loss_args)
+        if out.is_cuda and self.loss_args["aux"]:
+            loss = charbonnier_edge_loss_hip(out.float(), hrs.float(), self.loss_args["eps"], self.loss_args["aux_ratio"])
+        else:
+            loss = charbonnier_edge_loss(out.float(), hrs.float(), **self.loss_args)
         loss.backward()
         self._flush()
         if self.reducer is not None:
