@@ -96,7 +96,9 @@ typedef struct vmg_conv_desc {
   int pixel_shuffle;
   int mt;   /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
   int deep; /* kernel variant: 0 = 2-slot weight ring, 1 = 3-slot counted-wait ring, 2 = K split over the 4 waves with
-              * weights read global->register (bf16, cout_tiles <= 5, mt 1) */
+              * weights read global->register (bf16, cout_tiles <= 5, mt 1), 4 = 1x1 with every wave its own pipeline: weights
+              * resident in registers, 16-row tiles through wave-private LDS (bf16, one dense source of <= 160 channels,
+              * cout_tiles 3 or 5, 16-byte aligned output rows) */
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);

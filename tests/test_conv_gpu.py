@@ -330,3 +330,33 @@ def test_conv_ksplit_pixel_shuffle():
     got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1, pixel_shuffle=True, deep=2)
     assert tuple(got.shape) == (N, 2 * H, 2 * W, C)
     _cmp(got, want, dtype, "k-split pixel shuffle conv")
+
+
+@pytest.mark.parametrize("tiles", [5, 3])
+@pytest.mark.parametrize("shape", [(1000, 144, 144), (114688, 144, 144), (4097, 144, 288), (300, 160, 48), (777, 64, 144), (50, 8, 16)])
+def test_linear_wave_autonomous_variant(shape, tiles):
+    """The wave-autonomous 1x1 kernel (deep=4: weights resident in registers, 16-row tiles through wave-private LDS) against
+    torch: ragged M, several tiles per wave, both block sizes, every 16-byte epilogue; shapes it does not cover (padded LDS
+    stride at 64 channels) silently take the general kernel.  Results must be identical run to run."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    M, Ci, Co = shape
+    x = R.seeded((M, Ci), 71)
+    w = R.seeded((Co, Ci), 72, Ci ** -0.5)
+    b = R.seeded((Co,), 73, 0.1)
+    pre = F.linear(_q(x, dtype), _q(w, dtype), b)
+    pw = K.pack_conv_weight(w.cuda(), dtype, cout_tiles=tiles)
+    xd = x.cuda().to(dtype)
+    got, got_pre = K.conv_forward([xd], pw, b.cuda(), 1, 1, M, act=hip.ACT_GELU, want_pre=True, deep=4)
+    _cmp(got_pre.reshape(M, Co), pre, dtype, f"wave-autonomous linear pre {shape}")
+    _cmp(got.reshape(M, Co), F.gelu(pre), dtype, f"wave-autonomous linear gelu {shape}")
+    aux, res = R.seeded((M, Co), 74), R.seeded((M, Co), 75)
+    want = _q(res, dtype) + 0.5 * pre * (_q(aux, dtype) > 0).float()
+    kw = dict(alpha=0.5, res=res.cuda().to(dtype).reshape(1, 1, M, Co), aux=aux.cuda().to(dtype).reshape(1, 1, M, Co), actgrad=1, deep=4)
+    got, _ = K.conv_forward([xd], pw, b.cuda(), 1, 1, M, **kw)
+    _cmp(got.reshape(M, Co), want, dtype, f"wave-autonomous linear mask+residual {shape}")
+    for _ in range(3):
+        again, _ = K.conv_forward([xd], pw, b.cuda(), 1, 1, M, **kw)
+        assert torch.equal(got, again)
+    got, _ = K.conv_forward([xd], pw, None, 1, 1, M, act=hip.ACT_RELU, alpha=1.0 / Ci, deep=4)
+    _cmp(got.reshape(M, Co), F.relu(F.linear(_q(x, dtype), _q(w, dtype))) / Ci, dtype, f"wave-autonomous linear relu/scale {shape}")

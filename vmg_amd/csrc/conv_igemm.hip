@@ -766,6 +766,102 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
   conv_stamp(a, wave, 7);
 }
 
+// ================================================================================================ wave-autonomous 1x1
+// 1x1 convolutions / Linears with a small K (<= 160 input channels, one source), bf16: HBM-bound (33 MB in, 33 MB out, 2 us of
+// MFMA at M = 114 688) but the general kernel spent 36 us on them -- 1 792 workgroups of 64 rows, each streaming the 41 KiB
+// weight block through the LDS ring for 45 MFMAs per wave.  Here EVERY WAVE IS ITS OWN PIPELINE: it keeps the whole weight
+// block of its output-channel block resident in registers (5 k-steps x NTB fragments), walks over consecutive 16-row tiles
+// of the (M, C) matrix, copies tile t+1 into a wave-private LDS buffer by LDS-DMA while it multiplies tile t, and runs the
+// 16-byte epilogue through a wave-private LDS patch.  No workgroup barrier anywhere; one counted s_waitcnt per tile.
+template <int NTB>
+__global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int ntiles, int tiles_per_wave) {
+  using T = bf16;
+  constexpr int KS = 1, CB = 16, NK = 5, NDMA = 5;  // <= 160 channels = 5 k-steps; a 16-row tile = <= 320 vectors = 5 x 1 KiB
+  constexpr int COB = NTB * 16;
+  constexpr int SS = stage_stride(KS, NTB, CB);
+  constexpr int KSB = 4 * COB * CB;
+  constexpr int XBUF = NDMA * 1024;
+  constexpr int WAVE_LDS = 2 * XBUF + ((EpiLds<NTB>::BYTES + 1023) & ~1023);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  char* xbuf = smem + wave * WAVE_LDS;
+  char* patch = xbuf + 2 * XBUF;
+  const int pixb = a.src_pixb[0], CH = a.src_ch[0] >> 3, nb = (CH + 3) >> 2;  // pixb == ch * 2 (dense)
+  const int vpp = CH;                                                         // 16-byte vectors per row
+  const long long ps_b = a.src_ps[0] * 2;
+  const int t0 = (blockIdx.x * 4 + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+  if (t0 >= t1) return;  // (whole wave; nothing below synchronises across waves)
+
+  // ---- resident weights: every k-step of this output-channel block (k-steps past the real ones are zero fragments)
+  Frag<T> wres[NK][NTB];
+  {
+    const char* wlane = a.wpack + (long long)cb * a.nstages * SS + g * (COB * CB) + px * CB;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int kc = min(k, nb - 1);
+      const char* p = wlane + (long long)(kc >> 1) * SS + (kc & 1) * KSB;
+#pragma unroll
+      for (int ct = 0; ct < NTB; ++ct) {
+        wres[k][ct].load(p + ct * 16 * CB);
+        if (k >= nb) wres[k][ct].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
+  // ---- lane constants of the tile copy: vector L = 64 i + lane of the [16 rows][vpp] list
+  int c_off[NDMA];
+  int c_row[NDMA];  // row of the vector, or 16 for lanes past the end of the list
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int L = 64 * i + lane;
+    const int r = (int)(((float)L + 0.5f) * (1.0f / (float)vpp));
+    c_row[i] = L < 16 * vpp ? r : 16;
+    c_off[i] = (int)(r * ps_b) + (L - r * vpp) * 16;
+  }
+  auto issue = [&](int t, int buf) {
+    const long long m0 = (long long)t * 16;
+    const char* origin = a.src[0] + m0 * ps_b;
+    const long long left = a.M - m0;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const bool ok = c_row[i] < 16 && c_row[i] < left;
+      const char* gp = ok ? origin + c_off[i] : reinterpret_cast<const char*>(&g_conv_zero16);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(xbuf + buf * XBUF + i * 1024), 16, 0, 0);
+    }
+  };
+  int boff[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) boff[k] = px * pixb + min(4 * k + g, CH - 1) * CB;
+
+  issue(t0, 0);
+  int buf = 0;
+  for (int t = t0; t < t1; ++t, buf ^= 1) {
+    const long long m0 = (long long)t * 16;
+    bf16x8 pre_res[EpiLds<NTB>::NIT], pre_aux[EpiLds<NTB>::NIT];
+    conv_epilogue_prefetch8<KS, NTB>(a, 0, 4, cb, 0, 0, 0, m0, lane, pre_res, pre_aux);
+    if (t + 1 < t1) {
+      issue(t + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // tile t (and its epilogue operands) landed; tile t+1 stays in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    f32x4 acc[NTB];
+#pragma unroll
+    for (int ct = 0; ct < NTB; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* xb = xbuf + buf * XBUF;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      Frag<T> xf;
+      xf.load(xb + boff[k]);
+#pragma unroll
+      for (int ct = 0; ct < NTB; ++ct) acc[ct] = mma(wres[k][ct], xf, acc[ct]);
+    }
+    conv_epilogue_lds8<KS, NTB>(a, acc, patch, 0, 4, cb, 0, 0, 0, m0, lane, pre_res, pre_aux, a.bias ? a.bias + cb * COB : nullptr);
+  }
+}
+
 // ------------------------------------------------------------------------------------------- packing
 struct PackK {
   const float* w;
@@ -928,6 +1024,32 @@ int dispatch_ksplit(const ConvK& k, int ntb, int ncb, int halo_total, hipStream_
   return -1;
 }
 
+template <int NTB>
+int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
+  constexpr int WAVE_LDS = 2 * 5 * 1024 + ((EpiLds<NTB>::BYTES + 1023) & ~1023);
+  const int lds = 4 * WAVE_LDS;
+  auto fn = linear_wres_kernel<NTB>;
+  static bool attr_set = false;
+  static int ncu = 256;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const long long ntiles = cdiv64(k.M, 16);
+  VMG_CHECK(ntiles > 0 && ntiles < (1ll << 31), "conv: bad tile count %lld", ntiles);
+  // two workgroups per CU over all output-channel blocks; at least 4 tiles per wave so the resident weights pay off
+  long long waves = (long long)(2 * ncu / ncb > 0 ? 2 * ncu / ncb : 1) * 4;
+  long long tpw = cdiv64(ntiles, waves);
+  if (tpw < 4) tpw = 4;
+  const long long nwg = cdiv64(cdiv64(ntiles, tpw), 4);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nwg, ncb), dim3(256), lds, st, k, (int)ntiles, (int)tpw);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 static unsigned long long* g_conv_stamps = nullptr;
@@ -1038,11 +1160,16 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   k.nstages = kt; k.halo_bytes = (halo + 1023) & ~1023;  // the LDS-DMA copy writes whole 1-KiB pieces
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
+  if (d->deep == 4 && d->dtype == VMG_BF16 && d->ks == 1 && n == 1 && k.src_ch[0] <= 160 && k.src_pixb[0] == k.src_ch[0] * 2 && k.vec8 &&
+      (ntb == 3 || ntb == 5)) {
+    // (a hint: anything it does not cover -- padded LDS stride, several sources, unaligned rows -- takes the general kernel below)
+    return ntb == 3 ? launch_linear_wres<3>(k, ncb, st) : launch_linear_wres<5>(k, ncb, st);
+  }
   if (d->deep == 2) {
     VMG_CHECK(d->dtype == VMG_BF16 && mt == 1, "conv_fwd: the k-split variant is bf16, mt = 1");
     return d->ks == 3 ? dispatch_ksplit<bf16, 3>(k, ntb, ncb, k.halo_bytes, st) : dispatch_ksplit<bf16, 1>(k, ntb, ncb, k.halo_bytes, st);
   }
-  const bool deep = d->deep != 0;
+  const bool deep = d->deep == 1;
   if (d->dtype == VMG_BF16) {
     if (d->ks == 3) {
       if (deep) return mt == 2 ? dispatch_ntb<bf16, 3, 2, true>(k, ntb, ncb, st) : dispatch_ntb<bf16, 3, 1, true>(k, ntb, ncb, st);

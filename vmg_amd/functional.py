@@ -24,13 +24,15 @@ def _pad_to(n: int, m: int = 8) -> int:
     return (n + m - 1) // m * m
 
 
-def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype):
+def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None):
     """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3, kernel
     durations): the 144-channel 3x3 convs run best on the K-split kernel (deep = 2) as 64-pixel x 48-channel workgroups
     (three cout blocks, no padded tile, 138 registers -> three workgroups per CU): 25 us at M = 32 768 (27 us with two
     blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
     if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
         return 3, 1, 2  # 288 (local_cnn): 151 us vs 247 us at 144 -> 288, M = 114 688; the 576-channel PixelShuffle convs were slower this way
+    if dtype == torch.bfloat16 and ks == 1 and cout == 144 and src_ch is not None and len(src_ch) == 1 and src_ch[0] == 144 and M >= 8192:
+        return 5, 1, 4  # the 144 -> 144 Linears (token mixers, proj): wave-autonomous kernel, 13 us vs 36 us at M = 114 688
     return None, 1, 0
 
 
@@ -178,7 +180,7 @@ class _Conv2d(torch.autograd.Function):
         dt = srcs[0].dtype
         src_ch = [s.shape[-1] for s in srcs]
         srcs_p = [_pad_channels(s) for s in srcs]
-        tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt)
+        tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt, src_ch)
         pw = packed(weight, dt, "fwd", src_ch, tiles=tiles)
         need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
         out, pre = K.conv_forward(srcs_p, pw, bias, N, H, W, act=act, slope=slope, alpha=alpha, res=res,
@@ -220,7 +222,7 @@ class _Conv2d(torch.autograd.Function):
         dpre_p = _pad_channels(dpre)
         for i, c in enumerate(ctx.src_ch):
             if ctx.needs_input_grad[4 + i]:
-                tiles, mt, deep = choose_tiling(N * H * W, c, ks, dpre.dtype)
+                tiles, mt, deep = choose_tiling(N * H * W, c, ks, dpre.dtype, [weight.shape[0]])
                 pw = packed(weight, dpre.dtype, "dgrad", None, off, c, tiles=tiles)
                 dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep)
                 d_srcs.append(dx.reshape(ctx.src_shapes[i]))
