@@ -31,8 +31,8 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
     blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
     if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
         return 3, 1, 2  # 288 (local_cnn): 151 us vs 247 us at 144 -> 288, M = 114 688; the 576-channel PixelShuffle convs were slower this way
-    if dtype == torch.bfloat16 and ks == 1 and cout == 144 and src_ch is not None and len(src_ch) == 1 and src_ch[0] == 144 and M >= 8192:
-        return 5, 1, 4  # the 144 -> 144 Linears (token mixers, proj): wave-autonomous kernel, 13 us vs 36 us at M = 114 688
+    if dtype == torch.bfloat16 and ks == 1 and cout == 144 and src_ch is not None and len(src_ch) == 1 and src_ch[0] == 144 and M >= 65536:
+        return 5, 1, 4  # the 144 -> 144 Linears of stage 0 (token mixers, proj): wave-autonomous kernel, 21 us vs 33 us at M = 114 688 (no gain at M = 32 768)
     return None, 1, 0
 
 
