@@ -495,13 +495,19 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
     b_off[j] = W3_DYV * 16 + ky * W2_XW * (W2_XC * 2) + (kx + 8 * lg + (li >> 2)) * (W2_XC * 2) + (itile * 16 + 4 * (li & 3)) * 2;
   }
 
+  // SIX unit slots, one barrier per TWO units.  Unit j lives in slot j % 6; iteration j multiplies unit j (fragments already in
+  // registers) and reads unit j+1's fragments.  At the barrier of an even j every wave has (a) waited for its share of units
+  // j+1 and j+2 (units j+3, j+4 stay in flight: the wait is counted) and (b) drained its reads of unit j; afterwards units
+  // j+5 and j+6 are issued into the slots of units j-1 and j.
   const long long nun = u_hi - u_lo;
-  if (nun > 0) issue(0);
-  if (nun > 1) issue(1);
-  if (nun > 2) issue(2);
-  if (nun > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (nun > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int j = 0; j < 5; ++j)
+    if (j < nun) issue(j);
+  {
+    const long long later = nun > 3 ? (nun > 4 ? 2 : 1) : 0;  // units 3, 4 may stay in flight
+    if (later == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   bf16x8 af[5], bfg[7];
@@ -511,33 +517,42 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
 #pragma unroll
     for (int j = 0; j < 7; ++j) bfg[j] = tr_read(smem + b_off[j], W2_XC * 2);
   }
-  int bn = 1;  // buffer of unit u+1
-  for (long long u = u_lo; u < u_hi; ++u) {
-    const bool has_next = u + 1 < u_hi;
-    if (u + 2 < u_hi) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // unit u+1 landed; unit u+2 (3 instructions per wave) stays in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit u are complete
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const int bu = bn == 0 ? 2 : bn - 1;  // buffer of unit u: free now
-    const char* src = smem + (has_next ? bn : bu) * W3_BUF;  // (last unit: re-read its own buffer; the values are not used)
+  int sn = 1;  // slot of unit j+1
+  for (long long j = 0; j < nun; ++j) {
+    const bool has_next = j + 1 < nun;
+    const bool sync = (j & 1) == 0;  // (j = 0 too: every wave's prologue reads of unit 0 must be done before unit 6 overwrites its slot)
+    if (sync) {
+      const long long later = (j + 3 < nun ? 1 : 0) + (j + 4 < nun ? 1 : 0);
+      if (later == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit j are complete
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    const int su = sn == 0 ? 5 : sn - 1;  // slot of unit j
+    const char* src = smem + (has_next ? sn : su) * W3_BUF;  // (last unit: re-read its own slot; the values are not used)
     bf16x8 an[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) an[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int jj = 0; jj < 7; ++jj) {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[j], acc[c][j], 0, 0, 0);
-      bfg[j] = tr_read(src + b_off[j], W2_XC * 2);
+      for (int c = 0; c < 5; ++c) acc[c][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[jj], acc[c][jj], 0, 0, 0);
+      bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
     }
     if (a.has_bias && q == 0 && blockIdx.y == 0) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
-    if (u + 3 < u_hi) issue(bu);  // (after the MFMAs were handed to the matrix pipe: the copy's address arithmetic runs in their shadow)
+    if ((j & 1) == 0) {  // behind the MFMAs: units j+5, j+6 -> the slots of units j-1 and j (free since this iteration's barrier)
+      const int s5 = su == 0 ? 5 : su - 1;
+      if (j + 5 < nun) issue(s5);
+      if (j + 6 < nun) issue(su);
+    }
 #pragma unroll
     for (int c = 0; c < 5; ++c) af[c] = an[c];
-    bn = bn == 2 ? 0 : bn + 1;
+    sn = sn == 5 ? 0 : sn + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
@@ -782,7 +797,7 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr3 = true;
   }
-  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 3 * W3_BUF, st, k);
+  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 6 * W3_BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
   const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
