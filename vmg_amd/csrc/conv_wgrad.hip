@@ -392,7 +392,7 @@ __device__ __forceinline__ float slab_sum_4waves(const float* __restrict__ slab,
 // tiles; with 256 registers the X fragment of the NEXT unit is read into the registers of the fragment just consumed,
 // so LDS reads run under the MFMAs.  Per unit the [dY tile | X tile] pair is one linear list of 1188 16-byte vectors
 // copied by LDS-DMA, three 1-KiB instructions per wave (lanes past the list or outside the image read a zero buffer):
-// the wait is COUNTED.  Three LDS buffers, one barrier per unit; slabs + ordered reduction as in v2.
+// the wait is COUNTED.  Six LDS unit slots, one barrier per two units; slab partials + ordered reduction.
 // =====================================================================================================
 constexpr int W3_WAVES = 8, W3_THREADS = 512, W3_SLOTS = 3;
 constexpr int W3_DYV = 576, W3_VECS = 576 + W2_XVEC;            // 1188 vectors per unit
@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __
 // Workgroup = 9 waves (cg, it); output tile 144 co x 144 ci, wave (cg, it) owns co tiles 3cg..3cg+2 x ci tiles 3it..3it+2
 // (9 accumulator tiles + the bias tile for it == 0).  A unit = 32 consecutive pixels of the flat pixel list: both tiles
 // ([32][144] bf16, 9 KiB each) arrive by LDS-DMA exactly as they lie in HBM, one 16-byte vector per thread and tile, and
-// are read TRANSPOSED (ds_read_b64_tr_b16).  Three LDS buffers, one barrier per unit (see the 3x3 kernel above); the LDS
+// are read TRANSPOSED (ds_read_b64_tr_b16).  Three LDS buffers, one barrier per unit: at the top of iteration u a wave waits for its own share of unit u, and the
+// barrier also tells it that nobody reads unit u-1's buffer any more, so unit u+2 may overwrite it; the LDS
 // footprint (54 KiB) and register use allow two workgroups per CU, whose barrier bubbles overlap.  The pixel list is
 // cut into S slabs; partial tiles go to the workspace and the reduce kernel adds them to dW in slab order.
 struct Lgrad2K {
