@@ -126,3 +126,14 @@ def test_train_loss_matches_reference_fixture_and_oracle_gradient():
     xo = inp["x"].clone().requires_grad_(True)
     O.charbonnier_edge_loss(xo, inp["y"]).backward()
     assert float((x.grad - xo.grad).abs().max()) <= 1e-6 * max(1e-3, float(xo.grad.abs().max()))
+
+
+def test_conv_descriptor_pack_matches_ctypes_layout():
+    """kernels.conv_forward fills vmg_conv_desc with one struct.pack_into: the format must hit every ctypes field."""
+    from vmg_amd import kernels as K
+    d = K._CONV_DESC
+    vals = (1, 3, 5, 2, 7, 9, 144, 2, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 41, 42, 43, 44, 45, 46, 47, 48, 49, 2, 0.25, 0.5, 1, 0, 1, 2)
+    K._CONV_PACK(d, 0, *vals)
+    got = (d.dtype, d.ks, d.cout_tiles, d.N, d.H, d.W, d.Cout, d.nsrc, *d.src, *d.src_ps, *d.src_ch, d.packed, d.bias, d.out, d.out_ps, d.out_pre,
+           d.res, d.res_ps, d.aux, d.aux_ps, d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt, d.deep)
+    assert got == vals

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from vmg_amd.data import synthetic_clip, synthetic_target
-from vmg_amd.train import TrainStep, charbonnier_edge_loss, FlatAdamW
+from vmg_amd.train import TrainStep, charbonnier_edge_loss_hip, FlatAdamW
 from vmg_amd import functional as FH
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -23,7 +23,7 @@ t_all0 = time.perf_counter()
 for _ in range(steps):
     t = [time.perf_counter()]
     out = ts.model(x); t.append(time.perf_counter())
-    loss = charbonnier_edge_loss(out.float(), y.float(), **ts.loss_args); t.append(time.perf_counter())
+    loss = charbonnier_edge_loss_hip(out.float(), y.float(), ts.loss_args["eps"], ts.loss_args["aux_ratio"]); t.append(time.perf_counter())
     loss.backward(); t.append(time.perf_counter())
     ts._flush(); t.append(time.perf_counter())
     if isinstance(ts.opt, FlatAdamW):
