@@ -49,9 +49,10 @@ int vmg_max_lds_bytes(void);
  *   multiple of 8 channels (one slice per tensor of a virtual channel concat).
  * Data-gradient packing (transpose_flip = 1): output channels = I[o0 : o0+on), K = O[src_off[0] : +src_ch[0])
  *   with taps mirrored -- conv(dY, pack) is then dX of the forward conv (stride 1, pad KS/2).
- * The packed image is [cout_block][chunk q][co in block][8] elements of `dtype`; its size in bytes is
- * returned by vmg_conv_pack_bytes.  `cout_tiles` (1, 4, 5, 7, 8 or 9) is the number of 16-channel tiles per block and
- * must be the value later passed to vmg_conv_fwd.
+ * The packed image is [cout_block][stage][k-step][4 K-chunks][co in block][8] elements of `dtype` (a stage = 3 taps of a
+ * 32-channel block for 3x3, two 32-channel blocks for 1x1; stages padded to 4 KiB); its size in bytes is returned by
+ * vmg_conv_pack_bytes.  `cout_tiles` (1, 3, 4, 5, 7, 8 or 9) is the number of 16-channel tiles per block and must be the
+ * value later passed to vmg_conv_fwd.
  * ---------------------------------------------------------------------------------------------- */
 int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles);
 int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
