@@ -289,6 +289,36 @@ def _():
     return dict(inputs=inputs, run=run, chunk_of=chunk_of, window_of=window_of, cfg=cfg)
 
 
+# ---- LR schedule (utils/lr_scheduler.py) --------------------------------------------------------------
+LR_SCHEDULES = {
+    "shipped": dict(T_period=[600000], restarts=None, weights=[1], eta_min=1e-7, base=[0.0, 2e-4],
+                    steps=[0, 1, 2, 3, 10, 100, 1000, 5000]),       # VMG-REDS-few_levels.yml:98-103 (consecutive stepping up to 5000)
+    "restarts": dict(T_period=[10, 20, 30], restarts=[10, 30], weights=[1, 0.5], eta_min=1e-7, base=[0.0, 2e-4],
+                     steps=list(range(0, 60))),
+}
+
+
+def oracle_lr(step, base, T_period, restarts, weights, eta_min):
+    """Closed form the recursion of utils/lr_scheduler.py:17-33 telescopes to (see vmg_amd.train.cosine_restart_lr)."""
+    import math
+    start, T, peak = 0, T_period[0], base
+    for i, r in enumerate(restarts or []):
+        if r > 0 and step >= r:
+            start, T, peak = r, T_period[i + 1], base * weights[i]
+    return eta_min + 0.5 * (peak - eta_min) * (1 + math.cos(math.pi * (step - start) / T))
+
+
+@case("lr_schedule")
+def _():
+    def run(sd, inp):
+        outs = []
+        for cfg in LR_SCHEDULES.values():
+            outs.append(torch.tensor([[oracle_lr(t, b, cfg["T_period"], cfg["restarts"], cfg["weights"], cfg["eta_min"]) for b in cfg["base"]]
+                                      for t in cfg["steps"]], dtype=torch.float64).float() * 1e4)  # x1e4: O(1) numbers for the fixture tolerance
+        return outs
+    return dict(inputs=lambda: {}, run=run, no_weights=True)
+
+
 # ---- fixture I/O -------------------------------------------------------------------------------------
 def save_fixture(path: str, shapes: Dict[str, List[int]], outs: List[torch.Tensor]):
     arrs = {"shapes": np.frombuffer(json.dumps(shapes).encode(), dtype=np.uint8)}

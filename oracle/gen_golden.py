@@ -170,6 +170,26 @@ def reference_side(name, case, mods):
     if name == "loss":
         crit = Ls.CharbonnierLoss(eps=1e-12, if_aux_loss=True, aux_ratio=0.005)
         return {}, [crit(inp["x"], inp["y"]).reshape(1)]
+    if name == "lr_schedule":
+        # the reference's scheduler itself, stepped over a dummy two-group optimizer (group 0 = the lr-0 SPyNet group)
+        import importlib.util
+        from . import cases as C
+        spec = importlib.util.spec_from_file_location("vmg_ref_lrs", os.path.join(REF, "utils", "lr_scheduler.py"))
+        LS = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(LS)
+        outs = []
+        for cfg in C.LR_SCHEDULES.values():
+            ps = [torch.nn.Parameter(torch.zeros(1)) for _ in cfg["base"]]
+            opt = torch.optim.AdamW([{"params": [p], "lr": b} for p, b in zip(ps, cfg["base"])], lr=2e-4)
+            sch = LS.CosineAnnealingLR_Restart(opt, cfg["T_period"], eta_min=cfg["eta_min"], restarts=cfg["restarts"], weights=cfg["weights"])
+            rows, want = [], set(cfg["steps"])
+            for t in range(max(cfg["steps"]) + 1):
+                if t in want:
+                    rows.append([g["lr"] for g in opt.param_groups])
+                opt.step()
+                sch.step()
+            outs.append(torch.tensor(rows, dtype=torch.float64).float() * 1e4)
+        return {}, outs
     if name.startswith("infer_"):
         # tools/Tester.py's window loops, called as unbound methods on a stub `self` (Tester.__init__ builds a model from a
         # checkpoint path and is not run); the third-party names its module imports come from oracle/_standins

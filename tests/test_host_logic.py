@@ -137,3 +137,18 @@ def test_conv_descriptor_pack_matches_ctypes_layout():
     got = (d.dtype, d.ks, d.cout_tiles, d.N, d.H, d.W, d.Cout, d.nsrc, *d.src, *d.src_ps, *d.src_ch, d.packed, d.bias, d.out, d.out_ps, d.out_pre,
            d.res, d.res_ps, d.aux, d.aux_ps, d.act, d.slope, d.alpha, d.actgrad, d.pixel_shuffle, d.mt, d.deep)
     assert got == vals
+
+
+def test_cosine_restart_lr_matches_reference_scheduler():
+    """vmg_amd.train.cosine_restart_lr against learning rates the reference's CosineAnnealingLR_Restart produced
+    (tests/golden/lr_schedule.npz): the shipped single-period config and one with two restarts and a weight."""
+    import os
+    import numpy as np
+    from oracle import cases as C
+    from vmg_amd.train import cosine_restart_lr
+    _, ref = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "lr_schedule.npz"))
+    for cfg, r in zip(C.LR_SCHEDULES.values(), ref):
+        got = np.array([[cosine_restart_lr(t, b, cfg["T_period"], cfg["restarts"], cfg["weights"], cfg["eta_min"]) for b in cfg["base"]]
+                        for t in cfg["steps"]], dtype=np.float64).reshape(-1) * 1e4
+        assert got.size == r["sub"].size
+        assert float(np.abs(got - r["sub"]).max()) <= 1e-5 * max(1.0, float(np.abs(r["sub"]).max()))

@@ -102,15 +102,16 @@ def charbonnier_edge_loss_hip(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-
 # ---------------------------------------------------------------------------------------------------------
 def cosine_restart_lr(step: int, base_lr: float, T_period: List[int], restarts: Optional[List[int]] = None,
                       weights: Optional[List[float]] = None, eta_min: float = 1e-7) -> float:
-    restarts = restarts or [0]
-    weights = weights or [1.0]
-    idx, start = 0, 0
-    for i, r in enumerate(restarts):
-        if step >= r:
-            idx, start = i, r
-    T = T_period[min(idx, len(T_period) - 1)]
-    w = weights[min(idx, len(weights) - 1)]
-    return eta_min + 0.5 * (base_lr * w - eta_min) * (1 + math.cos(math.pi * ((step - start) % T) / T))
+    """Closed form of CosineAnnealingLR_Restart (utils/lr_scheduler.py:5-33) at scheduler step `step`: before the first
+    restart the period is T_period[0] from step 0 and the peak is base_lr; from restart i (step restarts[i] > 0) on, the
+    period is T_period[i+1], counted from the restart, and the peak is base_lr * weights[i].  The reference's recursion
+    multiplies (lr - eta_min) by (1+cos(pi t/T)) / (1+cos(pi (t-1)/T)) per step, which telescopes to this expression (valid
+    while t <= T inside a period, which is how every shipped config is set up)."""
+    start, T, peak = 0, T_period[0], base_lr
+    for i, r in enumerate(restarts or []):
+        if r > 0 and step >= r:
+            start, T, peak = r, T_period[i + 1], base_lr * (weights[i] if weights else 1.0)
+    return eta_min + 0.5 * (peak - eta_min) * (1 + math.cos(math.pi * (step - start) / T))
 
 
 # ---------------------------------------------------------------------------------------------------------
