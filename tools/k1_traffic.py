@@ -3,7 +3,7 @@ PMC passes that give bench.py's roofline.traffic:   rocprofv3 --pmc FETCH_SIZE -
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vmg_amd import hip, kernels as K
+from vmg_amd import kernels as K
 
 N, H, W, C = 8, 64, 64, 144
 torch.manual_seed(0)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import struct
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 

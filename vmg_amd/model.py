@@ -16,9 +16,8 @@ There is no CPU path: calling the module on CPU tensors raises (vmg_amd.hip.HipE
 """
 from __future__ import annotations
 
-import math
 from fractions import Fraction
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import numpy as np
 import torch
@@ -27,7 +26,7 @@ import torch.nn.functional as F
 
 from . import functional as FH
 from . import hip
-from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, HipError
+from .hip import ACT_GELU, ACT_LRELU, ACT_RELU, HipError
 
 
 # ---------------------------------------------------------------------------------------------------------
