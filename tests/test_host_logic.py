@@ -152,3 +152,17 @@ def test_cosine_restart_lr_matches_reference_scheduler():
                         for t in cfg["steps"]], dtype=np.float64).reshape(-1) * 1e4
         assert got.size == r["sub"].size
         assert float(np.abs(got - r["sub"]).max()) <= 1e-5 * max(1.0, float(np.abs(r["sub"]).max()))
+
+
+def test_abi_argument_counts_match_the_header():
+    """Every prototype of include/vmg_hip.h has as many parameters as the ctypes signature in vmg_amd/hip.py binds
+    (an argument added on one side only would shift every later one)."""
+    from vmg_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "vmg_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|double|const char\*)\s+(vmg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) == len(hip.SIGNATURES)
+    for name, args in protos:
+        args = args.strip()
+        n = 0 if args in ("", "void") else args.count(",") + 1
+        assert n == len(hip.SIGNATURES[name][1]), f"{name}: header has {n} parameters, hip.py binds {len(hip.SIGNATURES[name][1])}"
