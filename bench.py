@@ -31,9 +31,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 
 def build_model(device):
     import vmg_amd
-    # tools/train.py:111 of the reference asks for cudnn autotuning; on ROCm that is MIOpen's find mode, used by the ops
-    # that stay on PyTorch-ROCm (SPyNet's 7x7 convs, the loss's Gaussian pyramids): measured -4 ms per step
-    torch.backends.cudnn.benchmark = os.environ.get("VMG_NO_AUTOTUNE") != "1"
+    # no MIOpen find mode (tools/train.py:111 of the reference asks for cudnn.benchmark): its search took 5 minutes of the driver's
+    # bench run for the few ops left on PyTorch-ROCm; VMG_AUTOTUNE=1 turns it back on
+    torch.backends.cudnn.benchmark = os.environ.get("VMG_AUTOTUNE") == "1"
     from vmg_amd.data import REDS_FEW_LEVELS
     torch.manual_seed(0)
     m = vmg_amd.VMG(num_frames=T, image_size=[64, 64], is_train=True, spynet_pretrained=None, compute_dtype=torch.bfloat16,
@@ -43,7 +43,9 @@ def build_model(device):
 
 
 def cpu_baseline(seconds_budget=30.0):
-    """The oracle (CPU restatement, fp32, all host cores) forward + loss + backward on a bounded sample of the workload."""
+    """The oracle (CPU restatement, fp32, all host cores): forward + loss + backward + AdamW.  Two legs: a short warm-up pass on
+    1 clip x 5 frames (thread pool start, reported on stderr only) and then ONE step of the bench's own job -- 4 clips x 7
+    frames x 64 x 64, the same batch shape as the GPU number, AdamW over every parameter included."""
     from oracle import cases as C
     from oracle import recipe as R
     from oracle import vmg_oracle as O
@@ -59,24 +61,28 @@ def cpu_baseline(seconds_budget=30.0):
     for k, v in sd.items():
         if v.dtype.is_floating_point and not R.is_buffer(k):
             v.requires_grad_(True)
-    x = R.synthetic_clip(1, 5, 64, 64, 7)
-    y = R.synthetic_target(x)
-    # repeat forward + loss + backward until about 12 s of CPU work are in (at least 2, at most 8 passes; the first one is
-    # reported separately on stderr because it also pays the thread-pool start)
-    t0 = time.time()
-    reps = 0
-    while reps < 2 or (time.time() - t0 < min(12.0, seconds_budget) and reps < 8):
-        out = O.vmg_forward(sd, cfg, x, mutate=False, call_index=1)
+    leaves = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+
+    def one_step(b, t, seed):
+        x = R.synthetic_clip(b, t, 64, 64, seed)
+        y = R.synthetic_target(x)
+        c = C.cfg_reds_few(T=t)
+        t0 = time.time()
+        out = O.vmg_forward(sd, c, x, mutate=False, call_index=1)
         loss = O.charbonnier_edge_loss(out, y)
         loss.backward()
-        for v in sd.values():
-            if v.grad is not None:
-                v.grad = None
-        reps += 1
-        print("[bench] cpu_baseline pass %d done at %.1f s" % (reps, time.time() - t0), file=sys.stderr, flush=True)
-    dt = time.time() - t0
-    return {"value": round(5.0 * reps / dt, 4), "unit": "LR-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 clip x 5 frames x 64x64, fp32, forward+loss+backward x %d (%.1f s)" % (reps, dt)}
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return time.time() - t0
+
+    warm = one_step(1, 5, 7)
+    print("[bench] cpu_baseline warm-up pass (1x5x64x64) %.1f s" % warm, file=sys.stderr, flush=True)
+    dt = one_step(B_PER_GPU, T, 8)
+    print("[bench] cpu_baseline step (%dx%dx64x64) %.1f s" % (B_PER_GPU, T, dt), file=sys.stderr, flush=True)
+    return {"value": round(B_PER_GPU * T / dt, 4), "unit": "LR-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "one train step of the bench's own job: %d clips x %d frames x 64x64, fp32, forward+loss+backward+AdamW (%.1f s; "
+                      "warm-up pass on 1x5x64x64 before it: %.1f s)" % (B_PER_GPU, T, dt, warm)}
 
 
 def main():
@@ -90,10 +96,26 @@ def main():
                     "HIP-event roofline needs eager launches, so eager is the default)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU, RCCL) as CHILD processes and pass rank 0's
+        # JSON line through.  This parent never touches the GPU (no HIP call, no torch.cuda.* besides nothing at all).
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): refusing to report a different job" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the VMG hot path has no CPU fallback")
     # rehearsal on a one-GPU box: VMG_REHEARSE_ONE_GPU=1 puts every rank on device 0 and exchanges gradients over gloo (the
@@ -146,8 +168,8 @@ def main():
     null_us = 0.0
     if not args.no_prof:
         null_us = float(lib.vmg_prof_null_interval_us(50, hip.stream_ptr()))  # event-pair interval of an empty kernel
-        hip.check(lib.vmg_prof_select_pixels(K1_PIXELS), "vmg_prof_select_pixels")
-        hip.check(lib.vmg_prof_begin(1, 16, 4096), "vmg_prof_begin")
+        hip.check(lib.vmg_prof_select_pixels(hip.ctx(), K1_PIXELS), "vmg_prof_select_pixels")
+        hip.check(lib.vmg_prof_begin(hip.ctx(), 1, 16, 4096), "vmg_prof_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(lrs, hrs)
@@ -161,7 +183,7 @@ def main():
     roofline = None
     if not args.no_prof:
         seen, n, ms = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0.0)
-        hip.check(lib.vmg_prof_end(ctypes.byref(seen), ctypes.byref(n), ctypes.byref(ms)), "vmg_prof_end")
+        hip.check(lib.vmg_prof_end(hip.ctx(), ctypes.byref(seen), ctypes.byref(n), ctypes.byref(ms)), "vmg_prof_end")
         if n.value > 0:
             raw_us = ms.value / n.value * 1e3
             # `achieved` is priced on the RAW event-pair interval (conservative): it contains the event/dispatch latency that

@@ -37,6 +37,18 @@ extern "C" {
 
 const char* vmg_last_error(void);
 int vmg_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-device context.  The library keeps no process-global mutable state besides one handle per device:
+ * the handle owns the live profiler below and the device facts the launchers cache.  vmg_create(device) returns the
+ * device's handle (creating it on first use, reference-counted), vmg_destroy releases it.  A handle is used by one host
+ * thread at a time.  The kernel entry points themselves are stateless: they take raw pointers and a stream and use the
+ * CURRENT device (hipGetDevice) -- all pointers of a call must belong to it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vmg_ctx vmg_ctx;
+vmg_ctx* vmg_create(int device);   /* NULL on error (vmg_last_error) */
+int vmg_destroy(vmg_ctx* ctx);
+int vmg_ctx_device(const vmg_ctx* ctx);
 /* number of bytes of dynamic LDS the largest kernel instance requests (diagnostics) */
 int vmg_max_lds_bytes(void);
 
@@ -204,10 +216,10 @@ int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* 
  * and data-gradient alike) until `max_samples` pairs are used.  vmg_prof_end synchronises those events and
  * returns the number of launches seen, the samples taken and their summed duration in milliseconds.
  * ---------------------------------------------------------------------------------------------- */
-int vmg_prof_begin(int klass, int stride, int max_samples);
-int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms);
+int vmg_prof_begin(vmg_ctx* ctx, int klass, int stride, int max_samples);
+int vmg_prof_end(vmg_ctx* ctx, int64_t* launches_seen, int* samples, double* total_ms);
 /* restrict the timed launches to those over exactly `pixels` pixels (N*H*W); 0 = any size */
-int vmg_prof_select_pixels(int64_t pixels);
+int vmg_prof_select_pixels(vmg_ctx* ctx, int64_t pixels);
 /* event-pair interval (microseconds) around an empty one-wave kernel: the dispatch + event latency that the intervals
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);

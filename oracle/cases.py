@@ -53,6 +53,18 @@ def cfg_reds_few(T=5):
     return O.VMGConfig(num_frames=T)
 
 
+def cfg_reds_full(T=3):
+    """network block of configs/VMG-REDS.yml (the full 4-enc / 3-dec config, BASELINE configs[2]) with num_frames = T; the
+    keys that file lacks fall back to VMG.__init__ defaults: channel_mixer 'vanilla', if_local_fuse False."""
+    return O.VMGConfig(embed_dim=(112, 224, 224, 448, 224, 224, 112), depths=(4, 4, 2, 2, 2, 4, 4), num_heads=(4, 8, 8, 16, 8, 8, 4),
+                       num_frames=T, window_sizes=((2, 8, 8), (4, 8, 8), (6, 8, 8), (8, 8, 8), (6, 8, 8), (4, 8, 8), (2, 8, 8)),
+                       mlp_ratio=6, n_groups=4, image_size=(64, 64), is_train=False, traj_win=(16, None, None, None),
+                       traj_keyframes_n=(3, None, None, None), traj_heads=(4, None, None, None),
+                       temporal_type=(False, None, None, None), temporal_empty=True, traj_res_n=(15, 0, 0, 0, 0, 0, 15),
+                       spatial_type=(False,) * 4, mdsc=True, chunk_ratios=("1/8", "1/4", "3/16", "1/8"), r_scaling=0.1,
+                       if_local_fuse=False, channel_mixer="vanilla")
+
+
 # ---- input builders --------------------------------------------------------------------------------
 def int_locations(n, t, h, w, seed):
     """Integer-valued tracked locations incl. a few out-of-range ones (as nearest/border warps of a pixel grid
@@ -218,12 +230,15 @@ def _():
     return dict(inputs=inputs, run=lambda sd, inp: [O.charbonnier_edge_loss(inp["x"], inp["y"]).reshape(1)], no_weights=True)
 
 
-def _vmg_case(cfg_fn, T, seed, calls=1):
+def _vmg_case(cfg_fn, T, seed, calls=1, mirror=False):
     def make():
         cfg = cfg_fn(T)
         chunk_of, window_of = R.vmg_chunk_lookup(cfg)
 
         def inputs():
+            if mirror:  # even T, second half = first half reversed: VMG.check_frames_mirror is true (models/vmg.py:426-432, 448-452)
+                half = R.synthetic_clip(1, T // 2, 64, 64, seed)
+                return {"x": torch.cat([half, half.flip(1)], 1).contiguous()}
             return {"x": R.synthetic_clip(1, T, 64, 64, seed)}
 
         def run(sd, inp):
@@ -236,6 +251,8 @@ case("vmg_tiny_few")(_vmg_case(cfg_tiny_few, 3, 40, calls=2))
 case("vmg_tiny_multi")(_vmg_case(cfg_tiny_multi, 3, 41))
 case("vmg_tiny_swin")(_vmg_case(lambda T: cfg_tiny_few(T, temporal_empty=False), 4, 42))
 case("vmg_reds_few_cfg1")(_vmg_case(cfg_reds_few, 5, 43))
+case("vmg_reds_full")(_vmg_case(cfg_reds_full, 3, 44))
+case("vmg_tiny_mirror")(_vmg_case(cfg_tiny_few, 4, 45, mirror=True))
 
 
 # ---- sliding-window inference harness (tools/Tester.py) ---------------------------------------------

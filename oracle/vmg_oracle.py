@@ -271,7 +271,7 @@ def rcab(sd: SD, p: str, x: Tensor) -> Tensor:
 def morphfc_decay(sd: SD, p: str, x: Tensor, chunk_h: int, chunk_w: int, mutate: bool = True,
                   call_index: int = 1) -> Tensor:
     """Enhanced_MorphFCs_decay.forward (models/function.py:743-805), config: non_linear, gating+symm tanh,
-    relu_scale, channel_mixer 'rcab'.
+    relu_scale; channel_mixer 'rcab' or 'vanilla' (decided by the keys present in ``sd``, as the module tree does).
 
     mutate=True reproduces the in-place weight decay (T1).  mutate=False leaves ``sd`` untouched and uses
     W * Gamma**call_index (elementwise power by repeated multiplication).
@@ -299,7 +299,10 @@ def morphfc_decay(sd: SD, p: str, x: Tensor, chunk_h: int, chunk_w: int, mutate:
     tw = F.relu(F.linear(tw, ww, sd[f"{p}mlp_w.0.bias"])) / Cw
     w = morph_untokens(tw, "w", chunk_w, Cw, H, W, C)
 
-    c = rcab(sd, f"{p}mlp_c.", x) / C
+    if f"{p}mlp_c.0.weight" in sd:  # channel_mixer 'vanilla' + non_linear: Sequential(Linear, ReLU) (models/function.py:640-644)
+        c = F.relu(F.linear(x, sd[f"{p}mlp_c.0.weight"], sd[f"{p}mlp_c.0.bias"])) / C
+    else:  # channel_mixer 'rcab' (models/function.py:645-646)
+        c = rcab(sd, f"{p}mlp_c.", x) / C
 
     a = (h + w + c).mean((1, 2, 3))  # (B,C)
     a = F.linear(a, sd[f"{p}reweight.fc1.weight"], sd[f"{p}reweight.fc1.bias"])

@@ -1,0 +1,80 @@
+"""Data-parallel training of the HIP model: two fresh child processes on GPU 0 exchange gradients over gloo and the exchanged
+gradients are compared with a single-process reference (the average of both ranks' local gradients on the same weights).
+
+  * 'reducer': the native path -- TrainStep = FlatAdamW + GradBucketReducer + deferred batched weight gradients (the callbacks of
+    functional.DEFERRED drive the buckets), incl. the re-layout of the flat buffers after the first step;
+  * 'ddp': what the reference's tools/Trainer.py:30,132-143 does -- torch DistributedDataParallel(find_unused_parameters=False)
+    under autocast + GradScaler + clip_grad_norm_ + AdamW; weight gradients flow through autograd (wgrad mode 'autograd')."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _local_grads(state, clip_seed, mode):
+    """Single-process gradients of one rank's sample on the weights a step started from."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from tests.util import build_product
+    from vmg_amd.train import charbonnier_edge_loss_hip
+    m = build_product(C.CASES["vmg_tiny_few"]["cfg"], torch.float32)
+    m.load_state_dict(state)
+    m.train()
+    x = R.synthetic_clip(1, 3, 64, 64, clip_seed).cuda()
+    y = R.synthetic_target(x.cpu()).cuda()
+    loss = charbonnier_edge_loss_hip(m(x).float(), y.float())
+    loss.backward()
+    return {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("mode", ["reducer", "ddp"])
+def test_two_rank_gradient_exchange_matches_single_process(mode, tmp_path):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_child.py"), mode, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+    res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    assert res[0]["wgrad_mode"] == ("deferred" if mode == "reducer" else "autograd")
+    if mode == "reducer":
+        assert res[0]["buckets"] >= 3
+    for it in range(2):
+        s0, s1 = res[0]["log"][it]["state"], res[1]["log"][it]["state"]
+        for k in s0:  # identical replicas: rank 0's weights and buffers were broadcast, and stay in step
+            assert torch.equal(s0[k], s1[k]), f"step {it}: {k} differs between the ranks"
+        want = None
+        for rank in range(2):
+            g = _local_grads(s0, 60 + rank, mode)
+            want = g if want is None else {n: want[n] + g[n] for n in g}
+        gmax = max(float(v.abs().max()) for v in want.values()) / 2
+        for n in want:
+            ref = want[n] / 2
+            for r in range(2):
+                got = res[r]["log"][it]["grads"][n]
+                scale = max(float(ref.abs().max()), 1e-4 * gmax)
+                err = float((got - ref).abs().max()) / scale
+                assert err <= 2e-3, f"{mode} step {it} rank {r}: {n} relative error {err:.2e}"

@@ -12,28 +12,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_tiny_swin", "vmg_tiny_multi"])
-def test_parameter_gradients_match_oracle_autograd(name):
-    from oracle import cases as C
+def _oracle_grads(sd, cfg, x, tgt):
     from oracle import recipe as R
     from oracle import vmg_oracle as O
-    from tests.util import build_product
-    from vmg_amd import functional as FH
-    case = C.CASES[name]
-    cfg = case["cfg"]
-    shapes, _ = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
-    sd = C.case_state_dict(case, shapes)
-    x = case["inputs"]()["x"]
-    tgt = R.synthetic_target(x)
-
-    m = build_product(cfg, torch.float32)
-    m.load_state_dict(sd)
-    m.train()  # cfg.is_train is False -> drop-path rates are 0, so train mode is deterministic
-    out = m(x.cuda())
-    loss = (out - tgt.cuda()).square().mean()
-    loss.backward()
-    FH.flush_deferred_wgrads()
-
     osd = {}
     for k, v in sd.items():
         v = v.clone()
@@ -47,7 +28,44 @@ def test_parameter_gradients_match_oracle_autograd(name):
     oout = O.vmg_forward(osd, cfg, x, mutate=False, call_index=0)
     oloss = (oout - tgt).square().mean()
     oloss.backward()
-    assert abs(float(loss) - float(oloss)) <= 1e-5 * max(1.0, abs(float(oloss)))
+    return osd, float(oloss)
+
+
+@pytest.mark.parametrize("mode", ["autograd", "deferred"])
+@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_tiny_swin", "vmg_tiny_multi"])
+def test_parameter_gradients_match_oracle_autograd(name, mode):
+    """Both weight-gradient modes (functional.set_wgrad_mode): 'autograd' returns every weight gradient through autograd,
+    'deferred' batches them per parameter and writes .grad when backward() ends.  NO explicit flush in either."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from oracle import vmg_oracle as O
+    from tests.util import build_product
+    from vmg_amd import functional as FH
+    case = C.CASES[name]
+    cfg = case["cfg"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"]
+    tgt = R.synthetic_target(x)
+
+    FH.set_wgrad_mode(mode)
+    try:
+        m = build_product(cfg, torch.float32)
+        m.load_state_dict(sd)
+        m.train()  # cfg.is_train is False -> drop-path rates are 0, so train mode is deterministic
+        if mode == "deferred":
+            # a grad-enabled forward that is never back-propagated (an eval / logging call, a dropped batch) must not disturb
+            # the next step: the weights decay once more in it (T1), so reload them afterwards
+            m(x.cuda())
+            m.load_state_dict(sd)
+        out = m(x.cuda())
+        loss = (out - tgt.cuda()).square().mean()
+        loss.backward()
+    finally:
+        FH.set_wgrad_mode("autograd")
+
+    osd, oloss = _oracle_grads(sd, cfg, x, tgt)
+    assert abs(float(loss) - oloss) <= 1e-5 * max(1.0, abs(oloss))
 
     worst = 0.0
     gmax = max(float(v.grad.abs().max()) for v in osd.values() if v.grad is not None)
@@ -62,3 +80,50 @@ def test_parameter_gradients_match_oracle_autograd(name):
         worst = max(worst, err)
         assert err <= 5e-3, f"{k}: relative gradient error {err:.3e} (scale {scale:.3e}, model max {gmax:.3e})"
     print(f"{name}: worst relative gradient error {worst:.2e}")
+
+
+def test_bf16_whole_model_gradients_few_levels():
+    """The benchmarked configuration's backward: VMG-REDS-few_levels (144 channels, 15-block recurrent chains), T = 7, bf16
+    activations, train mode with DropPath off, deferred batched weight gradients -- against the fp32 oracle's autograd on
+    the same weights and clip.  Stated bf16 tolerance: per parameter tensor, relative L2 error <= 0.12 where the
+    gradient carries weight (its L2 norm >= 1e-3 of the largest tensor norm), cosine similarity of the concatenated gradient
+    >= 0.995, loss within 2 % (bf16 rounds every activation to 8 bits; the fp32 path is held to 5e-3 above)."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from tests.util import build_product
+    from vmg_amd import functional as FH
+    cfg = C.cfg_reds_few(T=7)
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_reds_few_cfg1.npz"))
+    chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+    sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
+    # reference-style initial scale for the convs of the 15-block chains keeps activations O(1) through 31 convs
+    x = R.synthetic_clip(1, 7, 64, 64, 46)
+    tgt = R.synthetic_target(x)
+    FH.set_wgrad_mode("deferred")
+    try:
+        m = build_product(cfg, torch.bfloat16)
+        m.load_state_dict(sd)
+        m.train()
+        out = m(x.cuda())
+        loss = (out.float() - tgt.cuda()).square().mean()
+        loss.backward()
+    finally:
+        FH.set_wgrad_mode("autograd")
+    osd, oloss = _oracle_grads(sd, cfg, x, tgt)
+    assert abs(float(loss) - oloss) <= 2e-2 * max(1e-3, abs(oloss)), (float(loss), oloss)
+    norms = {k: float(osd[k].grad.norm()) for k, _ in m.named_parameters()}
+    nmax = max(norms.values())
+    dot = gg = ww = 0.0
+    worst = (0.0, None)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        g, w = p.grad.float().cpu().double(), osd[k].grad.double()
+        dot += float((g * w).sum()); gg += float((g * g).sum()); ww += float((w * w).sum())
+        if norms[k] >= 1e-3 * nmax:
+            rel = float((g - w).norm()) / norms[k]
+            if rel > worst[0]:
+                worst = (rel, k)
+    cos = dot / (gg ** 0.5 * ww ** 0.5)
+    print(f"bf16 few_levels gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}")
+    assert cos >= 0.995, cos
+    assert worst[0] <= 0.12, worst

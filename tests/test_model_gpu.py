@@ -34,7 +34,8 @@ def _run(name, dtype, calls):
     return got, want, ref_outs, inp
 
 
-@pytest.mark.parametrize("name,calls", [("vmg_tiny_few", 2), ("vmg_tiny_multi", 1), ("vmg_tiny_swin", 1), ("vmg_reds_few_cfg1", 1)])
+@pytest.mark.parametrize("name,calls", [("vmg_tiny_few", 2), ("vmg_tiny_multi", 1), ("vmg_tiny_swin", 1), ("vmg_reds_few_cfg1", 1),
+                                        ("vmg_reds_full", 1), ("vmg_tiny_mirror", 1)])
 def test_vmg_fp32_matches_oracle_and_reference(name, calls):
     from oracle import cases as C
     from oracle import recipe as R
@@ -57,7 +58,23 @@ def test_vmg_statefulness_call2_differs():
     assert float(((got[1] - got[0]) - (want[1] - want[0])).abs().max()) <= 1e-3
 
 
-@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_reds_few_cfg1"])
+def test_mirrored_clip_takes_the_mirror_branch():
+    """Even T with the second half the reversed first half: backward flows are the flipped forward flows (models/vmg.py:426-432,
+    :457-462); the product must take that branch (one SPyNet direction) and still match the oracle (case vmg_tiny_mirror above)."""
+    from oracle import cases as C
+    from tests.util import build_product
+    case = C.CASES["vmg_tiny_mirror"]
+    m = build_product(case["cfg"], torch.float32)
+    m.eval()
+    with torch.no_grad():
+        m(case["inputs"]()["x"].cuda())
+    assert m.frames_mirror is True
+    with torch.no_grad():
+        m(C.CASES["vmg_tiny_swin"]["inputs"]()["x"].cuda())  # T = 4, not mirrored
+    assert m.frames_mirror is False
+
+
+@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_reds_few_cfg1", "vmg_reds_full"])
 def test_vmg_bf16_tolerance(name):
     from oracle import recipe as R
     from tests.util import psnr

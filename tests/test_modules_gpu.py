@@ -1,0 +1,83 @@
+"""Per-module replays of the reference fixtures through the PRODUCT modules (HIP path), fp32 strict and bf16 with the stated
+tolerance: the widths of the full VMG-REDS configuration (112 / 224 channels, chunk 12 with its padded Ch = 228 and Hp = 24,
+groups = 4) as well as the 144-channel few_levels ones.  Each case is checked against the oracle on the same weights and
+against the numbers the unmodified reference produced (tests/golden/*.npz).
+
+bf16 tolerance (stated): max |diff| <= 3e-2 of the output scale (inputs and weights are rounded to bf16 by the product; the
+oracle runs fp32 on the unrounded values)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _build(name):
+    from vmg_amd import model as M
+    if name.startswith("morphfc"):
+        C, ch = (144, 8) if name == "morphfc_c144_chunk8" else (224, 12)
+        return M.Enhanced_MorphFCs_decay(C, ch, ch, qkv_bias=True, channel_mixer="rcab")
+    if name == "rcab_c144":
+        return M.RCAB(144)
+    if name == "mlp_cnn_c144":
+        return M.Mlp_cnn(144, exp_r=2, n_groups=1)
+    if name == "mlp_cnn_c112_g4":
+        return M.Mlp_cnn(112, exp_r=2, n_groups=4)
+    if name == "tab_c144":
+        return M.TAB(144, 8, 8, 2, 1, True, 0.0, "ffn_cnn", 1.0, "rcab")
+    if name == "updown_down":
+        return M.UpdownkeepSampling(144, 144, "down")
+    if name == "updown_up":
+        return M.UpdownkeepSampling(144, 144, "up")
+    raise KeyError(name)
+
+
+CALLS = {"morphfc_c144_chunk8": 3, "tab_c144": 2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["morphfc_c144_chunk8", "morphfc_c224_chunk12", "rcab_c144", "mlp_cnn_c144", "mlp_cnn_c112_g4", "tab_c144",
+                                  "updown_down", "updown_up"])
+def test_module_matches_oracle_and_reference_fixture(name, dtype):
+    from oracle import cases as C
+    case = C.CASES[name]
+    shapes, ref_outs = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"]
+    m = _build(name).cuda()
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    calls = CALLS.get(name, 1)
+    with torch.no_grad():
+        got = [m(x.cuda().to(dtype)).float().cpu() for _ in range(calls)]  # calls #1.. (the mixer weights decay in place, T1)
+        want = case["run"]({k: v.clone() for k, v in sd.items()}, {"x": x})
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for i, (g, w) in enumerate(zip(got, want)):
+        g = g.reshape(w.shape)
+        scale = max(1.0, float(w.abs().max()))
+        err = float((g - w).abs().max())
+        assert err <= tol * scale, f"{name} call {i + 1} ({dtype}): max |hip - oracle| = {err} (scale {scale})"
+        sub = C.subsample(g)
+        assert float(np.abs(sub - ref_outs[i]["sub"]).max()) <= tol * scale, f"{name} call {i + 1}: differs from the reference fixture"
+
+
+def test_spynet_matches_reference_fixture():
+    """SPyNet through the product module vs the oracle and the reference's own flows (fp32)."""
+    import vmg_amd
+    from oracle import cases as C
+    for name in ("spynet", "spynet_48x40"):
+        case = C.CASES[name]
+        shapes, ref_outs = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+        sd = C.case_state_dict(case, shapes)
+        inp = case["inputs"]()
+        m = vmg_amd.SPyNet(None).cuda()
+        m.load_state_dict({k[len("spynet."):]: v for k, v in sd.items()}, strict=True)
+        with torch.no_grad():
+            got = m(inp["ref"].cuda(), inp["supp"].cuda()).float().cpu()
+            want = case["run"]({k: v.clone() for k, v in sd.items()}, inp)[0]
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= 2e-3 * scale
+        assert float(np.abs(C.subsample(got) - ref_outs[0]["sub"]).max()) <= 2e-3 * scale

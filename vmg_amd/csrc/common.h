@@ -18,7 +18,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // per-thread error text (vmg_last_error)
 void vmg_set_error(const char* fmt, ...);
 
-// live timing hooks (runtime.hip); kernel classes: 1 = conv3x3 fwd/dgrad bf16 C<=160 -> C<=160, 2 = conv wgrad
+// per-device state (runtime.hip): everything the library remembers between calls hangs off the device's vmg_ctx
+constexpr int VMG_MAX_DEVICES = 64;
+int vmg_current_device();      // hipGetDevice, clamped to [0, VMG_MAX_DEVICES)
+int vmg_cu_count(int device);  // compute units of the device (cached in its context)
+
+// live timing hooks (runtime.hip); kernel classes: 1 = conv3x3 fwd/dgrad bf16 C<=160 -> C<=160, 2 = conv wgrad.
+// vmg_prof_before returns false at once unless a profiler has been armed with vmg_prof_begin on the current device's context.
 bool vmg_prof_before(int klass, long long pixels, hipStream_t st);
 void vmg_prof_after(hipStream_t st);
 #define VMG_PROF_CONV3X3 1

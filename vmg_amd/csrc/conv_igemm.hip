@@ -110,17 +110,28 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& w, const Frag<float>& x,
 __device__ uint4 g_conv_zero16;  // 16 zero bytes: the source of out-of-image lanes of the halo copy
 
 // diagnostics: wave-level time stamps (100 MHz constant clock) at phase boundaries of the k-split kernel
+// (compiled in only with -DVMG_DIAG: tools/conv_timeline.py, tools/conv_ablate.py; the shipped library carries neither the
+// stamps nor the ablation bits)
+#ifdef VMG_DIAG
+#define VMG_DBG(a, bit) ((a).dbg & (bit))
 __device__ __forceinline__ void conv_stamp(const ConvK& a, int wave, int slot) {
   if (a.stamps) {
     const unsigned long long t = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + slot] = t;
   }
 }
+#else
+#define VMG_DBG(a, bit) 0
+__device__ __forceinline__ void conv_stamp(const ConvK&, int, int) {}
+#endif
 
 // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Giving XCD j the j-th contiguous
 // eighth of the tile list makes spatially neighbouring tiles (which share halo rows) and both cout blocks of a tile
 // meet in the same L2 (speed only: nothing depends on the placement).  bit 128 of dbg disables it.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk, int dbg) {
+#ifndef VMG_DIAG
+  dbg = 0;
+#endif
   if ((nblk & 7) != 0 || (dbg & 128)) return bid;
   return (bid & 7) * (nblk >> 3) + (bid >> 3);
 }
@@ -139,7 +150,7 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
       const long long ps_b = a.src_ps[s] * ES;
       const int vpp = ch * ES / 16;  // 16-byte vectors per pixel
       const float inv_vpp = 1.0f / (float)vpp;
-      if (pixb == ch * ES && !(a.dbg & 4)) {
+      if (pixb == ch * ES && !VMG_DBG(a, 4)) {
         // Dense LDS pixel stride: the tile is ONE linear array of THH*TWH*vpp 16-byte vectors, copied by LDS-DMA (no
         // registers, 1 KiB per instruction).  Wave w issues instructions w, w+4, ... -- the same count on every wave --
         // and every lane always loads: a lane whose pixel lies outside the image (or past the end of the tile: the LDS
@@ -174,7 +185,7 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
         // Padded LDS pixel stride: through registers.  Loads are UNCONDITIONAL (out-of-image lanes read the tensor's
         // first vector and select zero afterwards): a load behind a per-element branch makes hipcc wait vmcnt(0) per
         // element; this way a batch of NB loads is in flight before the first LDS write.
-        const int total = (a.dbg & 4) ? 0 : THH * TWH * vpp;
+        const int total = VMG_DBG(a, 4) ? 0 : THH * TWH * vpp;
         constexpr int NB = 8;
         for (int i0 = tid; i0 < total; i0 += 256 * NB) {
           uint4 val[NB];
@@ -276,7 +287,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& a, const f32x4 (&
         n = (int)(t / a.H);
       }
     }
-    if (!valid || (a.dbg & 8)) return;
+    if (!valid || VMG_DBG(a, 8)) return;
     if (fast) {
 #pragma unroll
       for (int ct = 0; ct < NTB; ++ct) {
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + a.halo_bytes;
-  if (a.dbg & 16) return;
+  if (VMG_DBG(a, 16)) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   const int nstages = a.nstages;
   const char* wsrc = a.wpack + (long long)cb * nstages * SS + (wave * 1024 + lane * 16);
   auto issue_w = [&](int stage) {
-    if (a.dbg & 1) return;
+    if (VMG_DBG(a, 1)) return;
     const char* gsrc = wsrc + (long long)stage * SS;
     char* dst = wbuf + (stage % RING) * SS + wave * 1024;
 #pragma unroll
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
       pixp[mt] = halo + ((KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb);
     }
 
-    const int nst_s = ((a.dbg & 32) ? 0 : a.src_nst[s]);
+    const int nst_s = (VMG_DBG(a, 32) ? 0 : a.src_nst[s]);
     int cbk = 0, ky = 0;  // 3x3: stage = (channel block cbk, tap row ky); 1x1: stage = channel blocks 2*sl, 2*sl+1
     for (int sl = 0; sl < nst_s; ++sl, ++gst) {
       // Stage gst must have landed, and every wave must be past stage gst-1 before its slot is refilled.
@@ -531,7 +542,7 @@ __device__ __forceinline__ void conv_epilogue_lds8(const ConvK& a, const f32x4 (
     long long pix;
     const bool valid = conv_row_pixel<KS>(a, row, TH, n, ty, tx, m0, pxi & 15, pix);
     const int co = cb * E::COB + c8 * 8;
-    if (!(j < 16 * E::C8 && valid && co < a.Cout) || (a.dbg & 8)) continue;
+    if (!(j < 16 * E::C8 && valid && co < a.Cout) || VMG_DBG(a, 8)) continue;
     const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + pxi * E::PSTR + c8 * 32);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + pxi * E::PSTR + c8 * 32 + 16);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
   char* halo = smem;                     // halo tile; after the main loop: reduce scratch, 12 slots of NTB KiB
   char* zslot = smem + a.halo_bytes;     // 16 zero bytes
   float* lbias = reinterpret_cast<float*>(zslot + 16);
-  if (a.dbg & 16) return;
+  if (VMG_DBG(a, 16)) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
     __syncthreads();
     conv_stamp(a, wave, 4);
 
-    const int nks = (a.dbg & 32) ? 0 : (KS == 3 ? 9 * nb : nb);  // k-steps of this source
+    const int nks = VMG_DBG(a, 32) ? 0 : (KS == 3 ? 9 * nb : nb);  // k-steps of this source
     const int per = ((nks + 3) / 4 + 2) / 3 * 3;                 // per wave, padded to the unroll
     const int k0 = wave * per;
     const int rowb = TWH * pixb;  // LDS bytes per tile row (KS == 1: TWH = 16 pixels)
@@ -960,10 +971,11 @@ int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
   const int lds = k.halo_bytes + (DEEP ? 3 : 2) * stage_stride(KS, NTB, CB);
   VMG_CHECK(lds <= 160 * 1024, "conv: LDS request %d B exceeds 160 KiB", lds);
   auto fn = conv_igemm_kernel<T, KS, MT, NTB, DEEP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[VMG_MAX_DEVICES] = {};  // the attribute is per device (one code object per device)
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
@@ -996,10 +1008,11 @@ int launch_ksplit(const ConvK& k, int ncb, int halo_total, hipStream_t st) {
   const int lds = (halo_total > scratch ? halo_total : scratch) + 16 + NTB * 16 * 4;
   VMG_CHECK(lds <= 160 * 1024, "conv (k-split): LDS request %d B exceeds 160 KiB", lds);
   auto fn = conv_ksplit_kernel<T, KS, NTB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[VMG_MAX_DEVICES] = {};  // the attribute is per device (one code object per device)
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
@@ -1029,15 +1042,13 @@ int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
   constexpr int WAVE_LDS = 2 * 5 * 1024 + ((EpiLds<NTB>::BYTES + 1023) & ~1023);
   const int lds = 4 * WAVE_LDS;
   auto fn = linear_wres_kernel<NTB>;
-  static bool attr_set = false;
-  static int ncu = 256;
-  if (!attr_set) {
+  static bool attr_set[VMG_MAX_DEVICES] = {};
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    attr_set = true;
+    attr_set[dev] = true;
   }
+  const int ncu = vmg_cu_count(dev);
   const long long ntiles = cdiv64(k.M, 16);
   VMG_CHECK(ntiles > 0 && ntiles < (1ll << 31), "conv: bad tile count %lld", ntiles);
   // two workgroups per CU over all output-channel blocks; at least 4 tiles per wave so the resident weights pay off
@@ -1052,10 +1063,18 @@ int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
 
 }  // namespace
 
+#ifdef VMG_DIAG
 static unsigned long long* g_conv_stamps = nullptr;
-extern "C" int vmg_conv_debug_stamps(void* buf) {  // diagnostics only (tools/conv_timeline.py); buf: 8 * 4 * workgroups uint64, or null
+#endif
+extern "C" int vmg_conv_debug_stamps(void* buf) {  // diagnostics builds only (tools/conv_timeline.py); buf: 8 * 4 * workgroups uint64, or null
+#ifdef VMG_DIAG
   g_conv_stamps = (unsigned long long*)buf;
   return 0;
+#else
+  (void)buf;
+  vmg_set_error("conv_debug_stamps: this library was built without -DVMG_DIAG (VMG_DIAG=1 python -m vmg_amd.build)");
+  return -1;
+#endif
 }
 
 extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles) {
@@ -1121,6 +1140,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   if (d->dtype == VMG_F32) mt = 1;
   const long long M = (long long)d->N * d->H * d->W;
   const int ntb = d->cout_tiles;
+  VMG_CHECK(ntb > 0, "conv_fwd: cout_tiles must be positive");
   const int ncb = cdiv(d->Cout, ntb * 16);
   if (mt == 0) mt = 1;  // measured (tools/bench_conv.py): one 16-pixel row per wave keeps 2 workgroups per CU and wins everywhere
   VMG_CHECK(mt == 1 || mt == 2, "conv_fwd: mt must be 1 or 2");
@@ -1146,11 +1166,13 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.M = M;
   k.tiles_x = cdiv(d->W, 16); k.tiles_y = cdiv(d->H, TH);
   k.act = d->act; k.slope = d->slope; k.alpha = d->alpha; k.actgrad = d->aux ? d->actgrad : 0; k.ps = d->pixel_shuffle;
+#ifdef VMG_DIAG
   {
     const char* e = getenv("VMG_CONV_DBG");  // ablation bits for tools/conv_ablate.py; read per call so one process can sweep
     k.dbg = e ? atoi(e) : 0;
     k.stamps = g_conv_stamps;
   }
+#endif
   {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     k.vec8 = d->dtype == VMG_BF16 && !d->pixel_shuffle && (d->Cout % 16) == 0 && (d->out_ps % 8) == 0 && al(d->out) &&

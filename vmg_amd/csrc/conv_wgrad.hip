@@ -273,10 +273,11 @@ int launch_wgrad(WgradK k, hipStream_t st) {
   if (s > 65535) s = 65535;
   k.S = (int)s;
   auto fn = conv_wgrad_kernel<T, KS, CT, IT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[VMG_MAX_DEVICES] = {};  // the attribute is per device
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(fn, dim3(gx, gy, k.S), dim3(256), C::LDS_BYTES, st, k);
   VMG_LAUNCH_CHECK();

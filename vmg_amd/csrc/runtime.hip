@@ -17,58 +17,127 @@ extern "C" int vmg_version(void) { return 100; }
 extern "C" int vmg_max_lds_bytes(void) { return 160 * 1024; }
 
 // ------------------------------------------------------------------------------------------------------
-// Live kernel timing for bench.py's roofline object: HIP events recorded on the launch stream around every
-// `stride`-th launch of the kernel class selected with vmg_prof_begin.  Reading the result synchronises.
+// Per-device context.  The library keeps NO process-global mutable state besides this table of per-device handles:
+// a vmg_ctx owns the live profiler (HIP events recorded on the launch stream around every `stride`-th launch of the kernel
+// class selected with vmg_prof_begin; reading the result synchronises) and the device facts the launchers cache.
+// A context is used by one host thread at a time; creation / destruction are serialised by a mutex.
 // ------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
 #include <vector>
-namespace {
-struct Prof {
+
+struct vmg_ctx {
+  int device = 0;
+  int refs = 0;
+  int cu_count = 0;
+  // profiler
   int klass = 0, stride = 1;
   long long seen = 0, pixels = 0;  // pixels: only launches over exactly this many pixels are timed (0 = any)
-  std::vector<hipEvent_t> ev;  // start/stop pairs
+  std::vector<hipEvent_t> ev;      // start/stop pairs
   size_t used = 0;
-} g_prof;
+};
+
+namespace {
+std::mutex g_ctx_mutex;
+vmg_ctx* g_ctx[VMG_MAX_DEVICES] = {};
+std::atomic<int> g_prof_armed{0};  // number of contexts with an armed profiler: the launch hooks return at once when 0
 }  // namespace
 
+int vmg_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VMG_MAX_DEVICES) return 0;
+  return dev;
+}
+
+static vmg_ctx* ctx_of(int device, bool create) {
+  if (device < 0 || device >= VMG_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if (!g_ctx[device] && create) {
+    vmg_ctx* c = new vmg_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    c->cu_count = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    g_ctx[device] = c;
+  }
+  return g_ctx[device];
+}
+
+int vmg_cu_count(int device) {
+  vmg_ctx* c = ctx_of(device, true);
+  return c ? c->cu_count : 256;
+}
+
+extern "C" vmg_ctx* vmg_create(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || device >= VMG_MAX_DEVICES) {
+    vmg_set_error("vmg_create: no such device %d", device);
+    return nullptr;
+  }
+  vmg_ctx* c = ctx_of(device, true);
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  ++c->refs;
+  return c;
+}
+
+extern "C" int vmg_destroy(vmg_ctx* c) {
+  VMG_CHECK(c != nullptr, "vmg_destroy: null context");
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  VMG_CHECK(c->device >= 0 && c->device < VMG_MAX_DEVICES && g_ctx[c->device] == c, "vmg_destroy: not a live context");
+  if (--c->refs > 0) return 0;
+  if (c->klass) g_prof_armed.fetch_sub(1);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  g_ctx[c->device] = nullptr;
+  delete c;
+  return 0;
+}
+
+extern "C" int vmg_ctx_device(const vmg_ctx* c) { return c ? c->device : -1; }
+
 bool vmg_prof_before(int klass, long long pixels, hipStream_t st) {
-  if (g_prof.klass == 0 || klass != g_prof.klass || (g_prof.pixels != 0 && pixels != g_prof.pixels)) return false;
-  if ((g_prof.seen++ % g_prof.stride) != 0 || g_prof.used + 2 > g_prof.ev.size()) return false;
-  (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  if (g_prof_armed.load(std::memory_order_relaxed) == 0) return false;
+  vmg_ctx* c = g_ctx[vmg_current_device()];
+  if (!c || c->klass == 0 || klass != c->klass || (c->pixels != 0 && pixels != c->pixels)) return false;
+  if ((c->seen++ % c->stride) != 0 || c->used + 2 > c->ev.size()) return false;
+  (void)hipEventRecord(c->ev[c->used], st);
   return true;
 }
 void vmg_prof_after(hipStream_t st) {
-  (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-  g_prof.used += 2;
+  vmg_ctx* c = g_ctx[vmg_current_device()];
+  if (!c) return;
+  (void)hipEventRecord(c->ev[c->used + 1], st);
+  c->used += 2;
 }
 
-extern "C" int vmg_prof_begin(int klass, int stride, int max_samples) {
-  VMG_CHECK(klass > 0 && stride > 0 && max_samples > 0, "prof_begin: bad arguments");
-  g_prof.klass = klass; g_prof.stride = stride; g_prof.seen = 0; g_prof.used = 0;
-  while (g_prof.ev.size() < (size_t)max_samples * 2) {
+extern "C" int vmg_prof_begin(vmg_ctx* c, int klass, int stride, int max_samples) {
+  VMG_CHECK(c && klass > 0 && stride > 0 && max_samples > 0, "prof_begin: bad arguments");
+  if (c->klass == 0) g_prof_armed.fetch_add(1);
+  c->klass = klass; c->stride = stride; c->seen = 0; c->used = 0;
+  while (c->ev.size() < (size_t)max_samples * 2) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) { vmg_set_error("prof_begin: hipEventCreate failed"); return -2; }
-    g_prof.ev.push_back(e);
+    c->ev.push_back(e);
   }
   return 0;
 }
 
-extern "C" int vmg_prof_select_pixels(int64_t pixels) {
-  VMG_CHECK(pixels >= 0, "prof_select_pixels: negative");
-  g_prof.pixels = pixels;
+extern "C" int vmg_prof_select_pixels(vmg_ctx* c, int64_t pixels) {
+  VMG_CHECK(c && pixels >= 0, "prof_select_pixels: bad arguments");
+  c->pixels = pixels;
   return 0;
 }
 
-extern "C" int vmg_prof_end(int64_t* launches_seen, int* samples, double* total_ms) {
-  VMG_CHECK(launches_seen && samples && total_ms, "prof_end: null pointer");
+extern "C" int vmg_prof_end(vmg_ctx* c, int64_t* launches_seen, int* samples, double* total_ms) {
+  VMG_CHECK(c && launches_seen && samples && total_ms, "prof_end: null pointer");
   double tot = 0.0;
   int n = 0;
-  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) continue;
+  for (size_t i = 0; i + 1 < c->used; i += 2) {
+    if (hipEventSynchronize(c->ev[i + 1]) != hipSuccess) continue;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) { tot += ms; ++n; }
+    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) { tot += ms; ++n; }
   }
-  *launches_seen = g_prof.seen; *samples = n; *total_ms = tot;
-  g_prof.klass = 0; g_prof.used = 0;
+  *launches_seen = c->seen; *samples = n; *total_ms = tot;
+  if (c->klass) g_prof_armed.fetch_sub(1);
+  c->klass = 0; c->used = 0;
   return 0;
 }
 

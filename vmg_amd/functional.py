@@ -107,23 +107,56 @@ def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:
 # 288 GB of HBM make keeping the pairs alive until then a non-issue.
 # ---------------------------------------------------------------------------------------------------------
 class _DeferredWgrad:
+    """mode 'autograd' (default): every conv / Linear backward computes its weight gradient at once and returns it through
+    autograd -- standard semantics, so torch DistributedDataParallel, GradScaler, clip_grad_norm_ and hooks all see it.
+    mode 'deferred' (vmg_amd.train.TrainStep switches it on): backward only records the pairs, see above.
+
+    Use counts are kept PER FORWARD PASS (a generation token taken in VMG.forward and stored in each autograd node), so
+    a grad-enabled forward that is never back-propagated (an eval / logging call, a batch dropped after an exception)
+    cannot leave counts behind that would silence a later step; and whatever is still pending when a backward() call ends
+    is flushed by an end-of-backward engine callback, so no caller has to flush explicitly."""
+
+    KEEP_GENERATIONS = 8
+
     def __init__(self):
-        self.uses = {}      # id(param) -> outstanding forward uses
+        self.mode = "autograd"
+        self.gen = 0
+        self.uses = {}      # (generation, id(param)) -> outstanding forward uses
         self.pending = {}   # id(param) -> [weight, bias, entries]
         self.callbacks = []  # called with each parameter whose .grad has just been completed
+        self._queued = False
 
-    def note_use(self, weight):
-        self.uses[id(weight)] = self.uses.get(id(weight), 0) + 1
+    def begin_forward(self):
+        """New top-level forward pass: a fresh generation; counts of passes older than KEEP_GENERATIONS are dropped."""
+        self.gen += 1
+        if self.uses:
+            lo = self.gen - self.KEEP_GENERATIONS
+            for key in [k for k in self.uses if k[0] < lo]:
+                del self.uses[key]
 
-    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0):
+    def note_use(self, weight) -> int:
+        key = (self.gen, id(weight))
+        self.uses[key] = self.uses.get(key, 0) + 1
+        return self.gen
+
+    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0):
         ent = self.pending.setdefault(id(weight), [weight, bias, []])
         ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale)))
-        left = self.uses.get(id(weight), 1) - 1
+        if not self._queued:  # whatever is still pending when this backward() call ends is completed then
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self._queued = True
+        key = (gen, id(weight))
+        left = self.uses.get(key, 1) - 1
         if left <= 0:
-            self.uses.pop(id(weight), None)
+            self.uses.pop(key, None)
             self.flush(weight)
         else:
-            self.uses[id(weight)] = left
+            self.uses[key] = left
+
+    def _end_of_backward(self):
+        self._queued = False
+        for key in list(self.pending):
+            self.flush(self.pending[key][0])
 
     def flush(self, weight):
         ent = self.pending.pop(id(weight), None)
@@ -135,32 +168,55 @@ class _DeferredWgrad:
         if bias is not None and bias.requires_grad and bias.grad is None:
             bias.grad = torch.zeros_like(bias, dtype=torch.float32)
         db = bias.grad if (bias is not None and bias.requires_grad) else None
-        groups = {}
-        for e in entries:
-            sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]), e[7])
-            groups.setdefault(sig, []).append(e)
-        for (src_ch, ks, N, H, W, _, _, scale), es in groups.items():
-            off = 0
-            for i, c in enumerate(src_ch):
-                xs = [e[0][i][..., :c] if e[0][i].shape[-1] != c else e[0][i] for e in es]
-                K.conv_wgrad_batched(xs, [e[2] for e in es], weight.grad, db if i == 0 else None, ks, N, H, W, scale=scale, i0=off)
-                off += c
+        _wgrad_entries(entries, weight.grad, db)
         for cb in self.callbacks:
             cb(weight)
             if db is not None:
                 cb(bias)
 
     def flush_all(self):
-        for key in list(self.pending):
-            self.flush(self.pending[key][0])
+        self._end_of_backward()
         self.uses.clear()
+
+
+def _wgrad_entries(entries, dW, db):
+    """dW (+= ) the weight gradient of every recorded (sources, src_ch, dpre, ks, N, H, W, scale) entry, batched by shape."""
+    groups = {}
+    for e in entries:
+        sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]), e[7])
+        groups.setdefault(sig, []).append(e)
+    for (src_ch, ks, N, H, W, _, _, scale), es in groups.items():
+        off = 0
+        for i, c in enumerate(src_ch):
+            xs = [e[0][i][..., :c] if e[0][i].shape[-1] != c else e[0][i] for e in es]
+            K.conv_wgrad_batched(xs, [e[2] for e in es], dW, db if i == 0 else None, ks, N, H, W, scale=scale, i0=off)
+            off += c
+
+
+def _wgrad_now(weight, bias_needed: bool, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0):
+    """(dW, db) of one use, as fresh fp32 tensors (mode 'autograd')."""
+    dW = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+    db = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device) if bias_needed else None
+    _wgrad_entries([(srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale))], dW, db)
+    return dW, db
 
 
 DEFERRED = _DeferredWgrad()
 
 
+def set_wgrad_mode(mode: str):
+    """'autograd' (default; weight gradients flow through autograd, DDP-compatible) or 'deferred' (batched per parameter,
+    written straight into .grad; the mode of vmg_amd.train.TrainStep / GradBucketReducer)."""
+    if mode not in ("autograd", "deferred"):
+        raise HipError(f"wgrad mode {mode!r}: 'autograd' or 'deferred'")
+    if mode != DEFERRED.mode:
+        DEFERRED.flush_all()
+        DEFERRED.mode = mode
+
+
 def flush_deferred_wgrads():
-    """Safety net after backward: completes gradients whose use count never reached zero (part of the graph unused)."""
+    """Completes every pending deferred gradient now (the end-of-backward callback does this by itself; kept for callers
+    that read .grad from inside a backward hook)."""
     DEFERRED.flush_all()
 
 
@@ -191,9 +247,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.res_shape = tuple(res.shape) if res is not None else None
         ctx.has_res = res is not None
         ctx.has_bias = bias is not None
-        ctx.defer = isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[0] and (bias is None or isinstance(bias, torch.nn.Parameter))
+        ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[0] and \
+            (bias is None or isinstance(bias, torch.nn.Parameter))
         if ctx.defer:
-            DEFERRED.note_use(weight)
+            ctx.gen = DEFERRED.note_use(weight)
             ctx.bias_ref = bias
         # relu / lrelu derivatives come from the sign of the output (taken before the residual is added, so keep
         # the sign information only when there is no residual; with a residual the activation is NONE on this path)
@@ -230,15 +287,11 @@ class _Conv2d(torch.autograd.Function):
                 d_srcs.append(None)
             off += c
         if ctx.defer:
-            DEFERRED.add(weight, ctx.bias_ref, list(srcs_p), ctx.src_ch, dpre, ks, N, H, W)
+            DEFERRED.add(weight, ctx.bias_ref, list(srcs_p), ctx.src_ch, dpre, ks, N, H, W, gen=ctx.gen)
         elif ctx.needs_input_grad[0]:
-            d_w = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
-            d_b = torch.zeros(O, dtype=torch.float32, device=weight.device) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
-            off = 0
-            for i, c in enumerate(ctx.src_ch):
-                K.conv_wgrad(srcs_p[i][..., :c] if srcs_p[i].shape[-1] != c else srcs_p[i], dpre, d_w, d_b if i == 0 else None,
-                             ks, N, H, W, i0=off)
-                off += c
+            d_w, d_b = _wgrad_now(weight, ctx.has_bias and ctx.needs_input_grad[1], list(srcs_p), ctx.src_ch, dpre, ks, N, H, W)
+            if weight.dim() == 2:
+                d_w = d_w.reshape(weight.shape)
         elif ctx.has_bias and ctx.needs_input_grad[1]:
             d_b = dpre.float().reshape(-1, O).sum(0)
         return (d_w, d_b, d_res, None, *d_srcs)
@@ -280,10 +333,11 @@ class _ResidualChain(torch.autograd.Function):
             y, _ = K.conv_forward([t], packed(w2, dt, "fwd", [C], tiles=tiles), b2, N, H, W, alpha=r_scaling, res=y, mt=mt, deep=deep)
             saved += [t, y]
         ctx.meta = (r_scaling, nsrc, nblk, N, H, W, src_ch, C)
-        ctx.defer = any(ctx.needs_input_grad[2 + nsrc:])
+        ctx.wgrad = any(ctx.needs_input_grad[2 + nsrc:])
+        ctx.defer = ctx.wgrad and DEFERRED.mode == "deferred"
         if ctx.defer:
             for p in params[0::2]:
-                DEFERRED.note_use(p)
+                ctx.gen = DEFERRED.note_use(p)
         ctx.params = params
         ctx.save_for_backward(*srcs, *saved[:-1])  # the final output is not needed
         return y
@@ -298,14 +352,18 @@ class _ResidualChain(torch.autograd.Function):
         dt = g.dtype
         M = N * H * W
         tiles, mt, deep = choose_tiling(M, C, 3, dt)
+        pg = [None] * len(params)  # parameter gradients returned through autograd (mode 'autograd')
         for k in range(nblk - 1, -1, -1):
             w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
             yk, tk = saved[2 * k], saved[2 * k + 1]
             # d t_k = r * dgrad2(g) masked by relu'(t_k)
             dt_k, _ = K.conv_forward([g], packed(w2, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, alpha=r, aux=tk, actgrad=1, mt=mt, deep=deep)
             if ctx.defer:
-                DEFERRED.add(w2, b2, [tk], [C], g, 3, N, H, W, scale=r)
-                DEFERRED.add(w1, b1, [yk], [C], dt_k, 3, N, H, W)
+                DEFERRED.add(w2, b2, [tk], [C], g, 3, N, H, W, scale=r, gen=ctx.gen)
+                DEFERRED.add(w1, b1, [yk], [C], dt_k, 3, N, H, W, gen=ctx.gen)
+            elif ctx.wgrad:
+                pg[4 + 4 * k], pg[5 + 4 * k] = _wgrad_now(w2, True, [tk], [C], g, 3, N, H, W, scale=r)
+                pg[2 + 4 * k], pg[3 + 4 * k] = _wgrad_now(w1, True, [yk], [C], dt_k, 3, N, H, W)
             # d y_k = g + dgrad1(d t_k)
             g, _ = K.conv_forward([dt_k], packed(w1, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, res=g, mt=mt, deep=deep)
         w0, b0 = params[0], params[1]
@@ -321,8 +379,10 @@ class _ResidualChain(torch.autograd.Function):
                 d_srcs.append(None)
             off += c
         if ctx.defer:
-            DEFERRED.add(w0, b0, srcs, src_ch, dpre0, 3, N, H, W)
-        return (None, None, *d_srcs, *([None] * len(params)))
+            DEFERRED.add(w0, b0, srcs, src_ch, dpre0, 3, N, H, W, gen=ctx.gen)
+        elif ctx.wgrad:
+            pg[0], pg[1] = _wgrad_now(w0, True, srcs, src_ch, dpre0, 3, N, H, W)
+        return (None, None, *d_srcs, *pg)
 
 
 def residual_chain(srcs: Sequence[torch.Tensor], conv0, blocks, r_scaling: float) -> torch.Tensor:

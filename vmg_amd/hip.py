@@ -70,7 +70,10 @@ SIGNATURES = {
                                     c_int, c_void_p]),
     "vmg_tile_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_conv_debug_stamps": (c_int, [c_void_p]),
-    "vmg_prof_select_pixels": (c_int, [c_int64]),
+    "vmg_create": (c_void_p, [c_int]),
+    "vmg_destroy": (c_int, [c_void_p]),
+    "vmg_ctx_device": (c_int, [c_void_p]),
+    "vmg_prof_select_pixels": (c_int, [c_void_p, c_int64]),
     "vmg_prof_null_interval_us": (ctypes.c_double, [c_int, c_void_p]),
     "vmg_conv_wgrad_ws_bytes": (c_int64, []),
     "vmg_conv_wgrad_batched_ws": (c_int, [c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int64, c_int,
@@ -78,8 +81,8 @@ SIGNATURES = {
     "vmg_group_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "vmg_tab_elementwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_int64, c_int, c_void_p]),
-    "vmg_prof_begin": (c_int, [c_int, c_int, c_int]),
-    "vmg_prof_end": (c_int, [POINTER(c_int64), POINTER(c_int), POINTER(ctypes.c_double)]),
+    "vmg_prof_begin": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "vmg_prof_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int), POINTER(ctypes.c_double)]),
     "vmg_conv_wgrad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
                                c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
 }
@@ -97,6 +100,22 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+_ctx = {}
+
+
+def ctx(device: int = None) -> int:
+    """The per-device handle (vmg_create), created on first use and kept for the life of the process."""
+    if device is None:
+        device = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+    h = _ctx.get(device)
+    if h is None:
+        h = lib().vmg_create(int(device))
+        if not h:
+            raise HipError(f"vmg_create({device}) failed: {lib().vmg_last_error().decode()}")
+        _ctx[device] = h
+    return h
 
 
 def check(rc: int, what: str):
@@ -125,6 +144,15 @@ def stream_ptr() -> int:
 
 
 def require_cuda(*tensors):
+    """Every tensor must live on the CURRENT device: kernels are enqueued on the current device's stream, and a pointer
+    of another GPU there is a memory fault, not a Python error (use torch.cuda.set_device / torch.cuda.device(...))."""
+    cur = -1
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise HipError("the VMG HIP path needs device tensors (there is no CPU fallback)")
+        if cur < 0:
+            cur = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+        if t.device.index != cur:
+            raise HipError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: call torch.cuda.set_device first")

@@ -202,9 +202,12 @@ class Enhanced_MorphFCs_decay(nn.Module):
         self.Cw = int(np.ceil(dim / chunk_w)) * chunk_w
         self.mlp_h = nn.Sequential(nn.Linear(self.Ch, self.Ch, bias=qkv_bias), nn.ReLU())
         self.mlp_w = nn.Sequential(nn.Linear(self.Cw, self.Cw, bias=qkv_bias), nn.ReLU())
-        if channel_mixer != "rcab":
-            raise NotImplementedError("channel_mixer must be 'rcab' (the only value a self-consistent shipped config uses)")
-        self.mlp_c = RCAB(n_feat=dim)
+        if channel_mixer == "rcab":
+            self.mlp_c = RCAB(n_feat=dim)
+        elif channel_mixer == "vanilla":  # VMG.__init__'s default, what VMG-REDS.yml (no such key) gets: Linear + ReLU (function.py:640-644)
+            self.mlp_c = nn.Sequential(nn.Linear(dim, dim, bias=qkv_bias), nn.ReLU())
+        else:
+            raise NotImplementedError(f"channel_mixer {channel_mixer!r}: 'rcab' or 'vanilla'")
         self.reweight = Mlp(dim, dim // 4, dim * 3)
         self.proj = nn.Linear(dim, dim)
         self.register_buffer("gamma_h", decay_gamma(chunk_h, self.Ch))
@@ -221,7 +224,10 @@ class Enhanced_MorphFCs_decay(nn.Module):
         tw = FH.morph_tokens(x, "w", self.chunk_w, self.Cw)
         tw = lin(self.mlp_w[0], tw, act=ACT_RELU, alpha=1.0 / self.Cw)
         w = FH.morph_untokens(tw, "w", self.chunk_w, self.Cw, H, W, C)
-        c = self.mlp_c(x, out_scale=1.0 / C)
+        if isinstance(self.mlp_c, RCAB):
+            c = self.mlp_c(x, out_scale=1.0 / C)
+        else:
+            c = lin(self.mlp_c[0], x, act=ACT_RELU, alpha=1.0 / C)
         rw = self.reweight
         y = FH.reweight_mix(h, w, c, rw.fc1.weight, rw.fc1.bias, rw.fc2.weight, rw.fc2.bias)
         y = lin(self.proj, y)
@@ -706,6 +712,15 @@ class VMG(nn.Module):
         if self.spynet is None:
             raise HipError("VMG.spynet is None: the trajectory modules need optical flow (the reference crashes here too, "
                            "models/trajectory.py:329); construct with spynet_pretrained or attach SPyNet(None)")
+        if torch.is_grad_enabled():
+            FH.DEFERRED.begin_forward()  # per-pass use counts of the deferred weight gradients (functional._DeferredWgrad)
+        # the kernels take fp32 / the module's compute dtype; an enclosing torch.autocast (tools/Trainer.py:132-143) must not
+        # re-type the few torch ops left in here
+        with torch.autocast("cuda", enabled=False):
+            return self._forward(x)
+
+    def _forward(self, x):
+        B, D, C, H, W = x.size()
         in_dtype = x.dtype
         x = x.float()
         self.check_frames_mirror(lrs=x)

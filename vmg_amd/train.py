@@ -120,56 +120,76 @@ def cosine_restart_lr(step: int, base_lr: float, T_period: List[int], restarts: 
 class GradBucketReducer:
     """Bucketed gradient all-reduce overlapped with backward (replaces DDP, tools/Trainer.py:30).
 
-    Parameters are bucketed in REVERSE registration order (roughly the order backward produces gradients: head,
-    decoder trajectory, ..., stem).  A post-accumulate-grad hook counts arrivals; when a bucket is complete its
-    gradients are packed into one flat buffer and an async all_reduce is launched on a side stream, so RCCL runs over
-    xGMI while the remaining backward kernels run.  finish() waits, divides by world size and unpacks.
-    xGMI is point-to-point (7 links per GPU): buckets are large (default 64 MB fp32) so each ring step moves multi-MB
-    messages per link; the whole 104 MB gradient of few_levels is 2 buckets.
+    A gradient-completion hook counts arrivals (autograd's post-accumulate hook, or the deferred batched weight gradient's
+    callback); when a bucket is complete an async all_reduce of it is launched on a side stream, so RCCL runs over xGMI
+    while the remaining backward kernels run.  finish() makes the compute stream wait for the side stream (no host block
+    with RCCL) and averages (ReduceOp.AVG on RCCL; SUM and one divide on gloo, which has no AVG).
+
+    Buckets are contiguous runs of the parameter ORDER, 8 MB by default: small enough that the first exchange starts a few
+    milliseconds into backward, large enough that a ring step still moves ~1 MB per xGMI link (7 links x ~153 GB/s per GPU,
+    point-to-point: a ring is bound by ONE link, so 8 MB takes ~0.1 ms).  The order starts as reverse registration order and,
+    with a FlatAdamW optimizer, is replaced after the first step by the MEASURED completion order of that step: the flat
+    parameter / gradient / moment buffers are re-laid out once (FlatAdamW.relayout) so that every bucket is again one
+    contiguous slice that is reduced in place -- no pack / unpack copies, and buckets complete in launch order.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None, flat_grad: Optional[torch.Tensor] = None,
-                 offsets: Optional[List[int]] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None, flat_grad: Optional[torch.Tensor] = None,
+                 offsets: Optional[List[int]] = None, optimizer=None):
         """flat_grad / offsets (FlatAdamW.g / .offsets, `params` in that order): the gradients already live in one flat
-        buffer, a bucket is a contiguous slice of it and is all-reduced IN PLACE -- no pack / unpack copies."""
+        buffer.  optimizer (a FlatAdamW): the same, plus the one-time re-layout by measured completion order."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_bytes = int(bucket_bytes)
+        self.optimizer = optimizer
+        if optimizer is not None:
+            params, flat_grad, offsets = optimizer.params, optimizer.g, optimizer.offsets
         self.params = [p for p in params if p.requires_grad]
         self.flat_grad = flat_grad
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.op_avg = backend == "nccl"  # RCCL averages in the collective
+        self.enabled = True
+        self.side = torch.cuda.Stream() if self.params[0].is_cuda else None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._order_log: List[torch.nn.Parameter] = []
+        self._relaid = optimizer is None  # nothing to re-lay out without a flat optimizer
+        try:  # conv / linear weights are completed by the deferred batched weight-gradient, not by autograd accumulation
+            from . import functional as FH
+            FH.DEFERRED.callbacks[:] = [self._on_grad]  # one reducer per process
+        except Exception:  # pragma: no cover
+            pass
+        if flat_grad is not None:
+            order = [p for _, p in sorted(zip(offsets, self.params), key=lambda t: -t[0])]  # reverse layout order
+        else:
+            order = list(reversed(self.params))
+        self._build(order, offsets)
+
+    def _build(self, order: List[torch.nn.Parameter], offsets: Optional[List[int]]):
+        """Buckets = runs of `order`; with a flat gradient buffer a run must be contiguous in it (any monotone walk is)."""
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
-        for p in reversed(self.params):
+        for p in order:
             cur.append(p)
             size += p.numel() * 4
-            if size >= bucket_bytes:
+            if size >= self.bucket_bytes:
                 self.buckets.append(cur)
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        if flat_grad is not None:
+        if self.flat_grad is not None:
             off_of = {id(p): o for p, o in zip(self.params, offsets)}
             self.flat = []
-            for b in self.buckets:  # parameters of a bucket are neighbours in the flat buffer (reverse order): one slice
+            for b in self.buckets:
                 lo = min(off_of[id(p)] for p in b)
                 hi = max(off_of[id(p)] + (p.numel() + 3) // 4 * 4 for p in b)
-                self.flat.append(flat_grad[lo:min(hi, flat_grad.numel())])
+                if hi - lo != sum((p.numel() + 3) // 4 * 4 for p in b):
+                    raise RuntimeError("GradBucketReducer: a bucket is not one contiguous slice of the flat gradient buffer")
+                self.flat.append(self.flat_grad[lo:min(hi, self.flat_grad.numel())])
         else:
             self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
         self.bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self.bucket_of[p] = bi
-        self.pending = [0] * len(self.buckets)
-        self.works = []
-        self.enabled = True
-        self.side = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self._seen = set()
-        try:  # conv / linear weights are completed by the deferred batched weight-gradient, not by autograd accumulation
-            from . import functional as FH
-            FH.DEFERRED.callbacks[:] = [self._on_grad]  # one reducer per process
-        except Exception:  # pragma: no cover
-            pass
         self.reset()
 
     def reset(self):
@@ -190,20 +210,26 @@ class GradBucketReducer:
         with ctx:
             if self.flat_grad is None:
                 torch._foreach_copy_(list(flat.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.op_avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not self.op_avg and self.side is not None:
+                work.wait()  # gloo: host-side wait; then the divide is queued behind it on the side stream
+                flat.div_(self.world)
+                work = None
         self.works.append((bi, work))
 
     def _on_grad(self, p: torch.nn.Parameter):
         if not self.enabled or p not in self.bucket_of or id(p) in self._seen:
             return
         self._seen.add(id(p))
+        if not self._relaid:
+            self._order_log.append(p)
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
             self._launch(bi)
 
     def finish(self):
-        """Wait for every bucket, average, and write the reduced gradients back into p.grad."""
+        """Wait for every bucket and leave the averaged gradients in p.grad."""
         if self.world > 1:
             missing = [bi for bi, n in enumerate(self.pending) if n > 0]
             for bi in missing:  # parameters that received no gradient this step still take part (zeros)
@@ -212,14 +238,32 @@ class GradBucketReducer:
                         p.grad = torch.zeros_like(p)
                 self._launch(bi)
             for bi, work in self.works:
-                work.wait()
+                if work is not None:
+                    work.wait()  # RCCL: the current stream waits for the collective, the host does not block
                 b, flat = self.buckets[bi], self.flat[bi]
-                if self.side is not None:
-                    torch.cuda.current_stream().wait_stream(self.side)
-                flat.div_(self.world)
+                if not self.op_avg and self.side is None:
+                    flat.div_(self.world)
                 if self.flat_grad is None:
+                    if self.side is not None:
+                        torch.cuda.current_stream().wait_stream(self.side)
                     torch._foreach_copy_([p.grad.reshape(-1) for p in b], list(flat.split([p.numel() for p in b])))
+            if self.side is not None:
+                torch.cuda.current_stream().wait_stream(self.side)
         self.reset()
+
+    def relayout_by_completion(self) -> bool:
+        """After the first full step (call it once the optimizer has consumed the gradients): re-home the flat buffers in the
+        measured gradient-completion order of that step and rebuild the buckets on it.  Returns True if it did."""
+        if self._relaid or self.optimizer is None or not self._order_log:
+            return False
+        seen = {id(p) for p in self._order_log}
+        order = self._order_log + [p for p in self.params if id(p) not in seen]  # never-completed parameters go last
+        self._order_log = []
+        self._relaid = True
+        self.optimizer.relayout(order)
+        self.params, self.flat_grad = self.optimizer.params, self.optimizer.g
+        self._build(list(self.optimizer.params), self.optimizer.offsets)
+        return True
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
@@ -289,6 +333,40 @@ class FlatAdamW:
     def param_groups(self):
         return self.groups
 
+    @torch.no_grad()
+    def relayout(self, order):
+        """Re-home parameters, gradients and moments so that, inside every parameter group, tensors follow `order` (a list of
+        all parameters, e.g. the measured gradient-completion order of a step).  One-time copy; group segments stay contiguous."""
+        rank = {id(p): i for i, p in enumerate(order)}
+        new_params = []
+        for g in self.groups:
+            g["params"] = sorted(g["params"], key=lambda p: rank.get(id(p), len(rank)))
+            new_params += g["params"]
+        old_off = {id(p): o for p, o in zip(self.params, self.offsets)}
+        offs, total = [], 0
+        for p in new_params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        assert total == self.n
+        np_, ng, nm, nv = (torch.zeros_like(self.p) for _ in range(4))
+        for p, o in zip(new_params, offs):
+            oo, n = old_off[id(p)], p.numel()
+            for dst, src in ((np_, self.p), (ng, self.g), (nm, self.m), (nv, self.v)):
+                dst[o:o + n].copy_(src[oo:oo + n])
+        self.p, self.g, self.m, self.v = np_, ng, nm, nv
+        self.params, self.offsets = new_params, offs
+        for p, o in zip(new_params, offs):
+            p.data = self.p[o:o + p.numel()].view_as(p)
+            p.grad = self.g[o:o + p.numel()].view_as(p)
+        k = 0
+        for g in self.groups:
+            n = len(g["params"])
+            g["start"] = offs[k] if n else total
+            g["end"] = (offs[k + n] if k + n < len(offs) else total) if n else total
+            k += n
+        from . import functional as FH
+        FH.bump_weight_epoch()  # parameter storage moved: cached weight packs are stale
+
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are persistent views of the flat buffer: one memset (set_to_none is accepted and ignored)."""
         self.g.zero_()
@@ -346,8 +424,10 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), weight_decay: float = 0.0, eps_loss: float = 1e-12,
                  aux: bool = True, aux_ratio: float = 0.005, spynet_lr: float = 0.0, distributed: bool = False,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 8 << 20):
         self.model = model
+        from . import functional as FH
+        FH.set_wgrad_mode("deferred")  # batched weight gradients written straight into the flat gradient buffer
         spy = list(model.spynet.parameters())
         spy_ids = {id(p) for p in spy}
         rest = [p for p in model.parameters() if id(p) not in spy_ids]
@@ -359,12 +439,13 @@ class TrainStep:
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
             self.opt = FlatAdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
-            self.reducer = GradBucketReducer(self.opt.params, bucket_bytes, flat_grad=self.opt.g, offsets=self.opt.offsets) if distributed else None
+            self.reducer = GradBucketReducer([], bucket_bytes, optimizer=self.opt) if distributed else None
         else:  # host-side rehearsals only (the model itself has no CPU path)
             self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
             self.reducer = GradBucketReducer(model.parameters(), bucket_bytes) if distributed else None
         self.graph = None
         self._static = None
+        self.grad_hook = None  # optional callable(TrainStep), run after the gradient exchange and before the optimizer (tests, logging)
         self.loss_args = dict(eps=eps_loss, aux=aux, aux_ratio=aux_ratio)
         if distributed:
             broadcast_module_state(model)
@@ -421,6 +502,8 @@ class TrainStep:
         self._flush()
         if self.reducer is not None:
             self.reducer.finish()
+        if self.grad_hook is not None:
+            self.grad_hook(self)
         if isinstance(self.opt, FlatAdamW):
             if self.graph is None and not torch.cuda.is_current_stream_capturing():
                 self.opt.advance()  # host scalars of this step (a captured graph gets them from replay())
@@ -430,4 +513,6 @@ class TrainStep:
         else:
             self.opt.step()
         self.opt.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.relayout_by_completion()  # once, after the first step: buckets follow the measured completion order
         return loss.detach()
