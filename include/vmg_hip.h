@@ -70,6 +70,14 @@ int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_
 int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
                   const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream);
 
+/* Packing for the weight-streaming 3x3 kernel (vmg_conv_fwd with deep = 3; bf16 only): same slicing arguments as
+ * vmg_conv_pack.  Image: [cout block][stage][3 k-steps][4 lane groups][co in block][8] bf16, a k-step = one tap of a 32-channel
+ * block, or -- for the last 16 channels of a block that is not a multiple of 32 -- two taps of 16 channels; cout_tiles 9 (blocks
+ * of 144 output channels) or 7 (112).  Channel slices must split into blocks of <= 160 channels that are multiples of 16. */
+int64_t vmg_convws_pack_bytes(int on, int nsrc, const int* src_ch, int cout_tiles);
+int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch, int transpose_flip,
+                    int cout_tiles, void* packed, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * vmg_conv_fwd -- stride-1 "same" convolution (KS = 3 or 1) as MFMA implicit GEMM with fused epilogue.
  *
@@ -109,7 +117,9 @@ typedef struct vmg_conv_desc {
   int pixel_shuffle;
   int mt;   /* 0 = auto; 16-pixel tiles per wave (1 or 2) */
   int deep; /* kernel variant: 0 = 2-slot weight ring, 1 = 3-slot counted-wait ring, 2 = K split over the 4 waves with
-              * weights read global->register (bf16, cout_tiles <= 5, mt 1), 4 = 1x1 with every wave its own pipeline: weights
+              * weights read global->register (bf16, cout_tiles <= 5, mt 1), 3 = weight-streaming 3x3 (bf16; 128-pixel tiles x 144 or
+              * 112 output channels per workgroup, loader waves stream the vmg_convws_pack image through an LDS ring; cout_tiles 9 or 7,
+              * 16-byte aligned rows, no pixel_shuffle), 4 = 1x1 with every wave its own pipeline: weights
               * resident in registers, 16-row tiles through wave-private LDS (bf16, one dense source of <= 160 channels,
               * cout_tiles 3 or 5, 16-byte aligned output rows) */
 } vmg_conv_desc;

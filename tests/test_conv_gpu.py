@@ -360,3 +360,79 @@ def test_linear_wave_autonomous_variant(shape, tiles):
         assert torch.equal(got, again)
     got, _ = K.conv_forward([xd], pw, None, 1, 1, M, act=hip.ACT_RELU, alpha=1.0 / Ci, deep=4)
     _cmp(got.reshape(M, Co), F.relu(F.linear(_q(x, dtype), _q(w, dtype))) / Ci, dtype, f"wave-autonomous linear relu/scale {shape}")
+
+
+# ---------------------------------------------------------------------------------------------- weight-streaming kernel
+@pytest.mark.parametrize("shape", [(2, 24, 20, 144, 144), (8, 64, 64, 144, 144), (3, 9, 17, 128, 144), (1, 16, 16, 144, 288), (1, 8, 8, 112, 224),
+                                   (2, 20, 33, 224, 112), (1, 12, 16, 448, 112), (1, 30, 50, 32, 144)])
+def test_conv_ws_bias_relu(shape):
+    """vmg_conv_fwd deep = 3 (128-pixel tiles, loader waves stream the weights through an LDS ring) vs the oracle; shapes cover
+    ragged image borders, both channel-block kinds (multiples of 32, and 16 left over), several channel blocks per source
+    (halo restage) and several output-channel blocks."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, Ci, Co = shape
+    x = R.seeded((N, H, W, Ci), 41)
+    w = R.seeded((Co, Ci, 3, 3), 42, (Ci * 9) ** -0.5)
+    b = R.seeded((Co,), 43, 0.1)
+    want = F.relu(O.conv_nhwc(_q(x, dtype), _q(w, dtype), b, 1))
+    tiles = K.ws_eligible(Co, 3, dtype, [Ci])
+    assert tiles in (7, 9)
+    pw = K.pack_conv_weight_ws(w.cuda(), cout_tiles=tiles)
+    got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_RELU, deep=3)
+    _cmp(got, want, dtype, f"conv ws {shape}")
+
+
+def test_conv_ws_concat_residual_gelu_pre_dgrad():
+    """The epilogues and operand forms the model uses with the weight-streaming kernel: virtual concat of two sources + LeakyReLU,
+    residual + scale, GELU with the pre-activation kept, data gradient with the ReLU mask, and both residual and mask at once."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, C = 2, 16, 32, 144
+    x1, x2 = R.seeded((N, H, W, C), 44), R.seeded((N, H, W, C), 45)
+    w = R.seeded((C, 2 * C, 3, 3), 46, (2 * C * 9) ** -0.5)
+    b = R.seeded((C,), 47, 0.1)
+    want = F.leaky_relu(O.conv_nhwc(torch.cat([_q(x1, dtype), _q(x2, dtype)], -1), _q(w, dtype), b, 1), 0.1)
+    pw = K.pack_conv_weight_ws(w.cuda(), src_ch=[C, C])
+    got, _ = K.conv_forward([x1.cuda().to(dtype), x2.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1)
+    _cmp(got, want, dtype, "ws concat conv")
+    w2 = R.seeded((C, C, 3, 3), 48, (C * 9) ** -0.5)
+    pw2 = K.pack_conv_weight_ws(w2.cuda())
+    want2 = _q(x1, dtype) + 0.1 * O.conv_nhwc(_q(x2, dtype), _q(w2, dtype), b, 1)
+    got2, _ = K.conv_forward([x2.cuda().to(dtype)], pw2, b.cuda(), N, H, W, alpha=0.1, res=x1.cuda().to(dtype))
+    _cmp(got2, want2, dtype, "ws residual conv")
+    pre = O.conv_nhwc(_q(x2, dtype), _q(w2, dtype), b, 1)
+    got3, got3_pre = K.conv_forward([x2.cuda().to(dtype)], pw2, b.cuda(), N, H, W, act=hip.ACT_GELU, want_pre=True)
+    _cmp(got3_pre, pre, dtype, "ws pre-activation")
+    _cmp(got3, F.gelu(pre), dtype, "ws gelu")
+    # data gradient with the ReLU mask of aux, and with a residual on top
+    xg = x2.clone().requires_grad_(True)
+    (dx,) = torch.autograd.grad(O.conv_nhwc(xg, _q(w2, dtype), None, 1), xg, _q(x1, dtype))
+    aux = R.seeded((N, H, W, C), 49)
+    pwd = K.pack_conv_weight_ws(w2.cuda(), transpose_flip=True)
+    got4, _ = K.conv_forward([x1.cuda().to(dtype)], pwd, None, N, H, W, aux=aux.cuda().to(dtype), actgrad=1, alpha=0.1)
+    _cmp(got4, 0.1 * dx * (_q(aux, dtype) > 0).float(), dtype, "ws dgrad + mask")
+    got5, _ = K.conv_forward([x1.cuda().to(dtype)], pwd, None, N, H, W, aux=aux.cuda().to(dtype), actgrad=1, res=x2.cuda().to(dtype))
+    _cmp(got5, dx * (_q(aux, dtype) > 0).float() + _q(x2, dtype), dtype, "ws dgrad + mask + residual")
+
+
+def test_conv_ws_repeatable_and_matches_ksplit():
+    """Same inputs, 20 launches back to back on a busy GPU: bit-identical outputs (no race between the loader waves' LDS-DMA and
+    the consumer waves' reads), and agreement with the K-split kernel to bf16 rounding."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, C = 8, 64, 64, 144
+    x = R.seeded((N, H, W, C), 50).cuda().to(dtype)
+    w = R.seeded((C, C, 3, 3), 51, (C * 9) ** -0.5).cuda()
+    b = R.seeded((C,), 52, 0.1).cuda()
+    pw = K.pack_conv_weight_ws(w)
+    pk = K.pack_conv_weight(w, dtype, cout_tiles=3)
+    ref, _ = K.conv_forward([x], pk, b, N, H, W, act=hip.ACT_RELU, deep=2)
+    first = None
+    for i in range(20):
+        got, _ = K.conv_forward([x], pw, b, N, H, W, act=hip.ACT_RELU)
+        if first is None:
+            first = got.clone()
+        else:
+            assert torch.equal(got, first), f"launch {i} differs from launch 0"
+    assert float((first.float() - ref.float()).abs().max()) <= 2e-2 * max(1.0, float(ref.float().abs().max()))

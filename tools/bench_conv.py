@@ -7,22 +7,25 @@ from vmg_amd import hip, kernels as K
 
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     torch.manual_seed(0)
     dtype = torch.bfloat16
     H = W = 64
-    for (Ci, Co, ks) in [(144, 144, 3), (144, 288, 3), (144, 144, 1)]:
+    for (Ci, Co) in [(144, 144), (288, 144), (144, 288)]:
         x = torch.randn(N, H, W, Ci, device="cuda").to(dtype)
-        w = torch.randn(Co, Ci, ks, ks, device="cuda") * (Ci * ks * ks) ** -0.5
+        r = torch.randn(N, H, W, Co, device="cuda").to(dtype)
+        w = torch.randn(Co, Ci, 3, 3, device="cuda") * (Ci * 9) ** -0.5
         b = torch.randn(Co, device="cuda")
         out = torch.empty(N, H, W, Co, device="cuda", dtype=dtype)
-        for tiles in (9, 5, 3):
-            pw = K.pack_conv_weight(w, dtype, cout_tiles=tiles)
-            for mt, deep in ((1, 0), (1, 2)) if tiles <= 5 else ((1, 0),):
-                for _ in range(reps):
-                    K.conv_forward([x], pw, b, N, H, W, act=hip.ACT_RELU, out=out, mt=mt, deep=deep)
-                torch.cuda.synchronize()
+        pk = K.pack_conv_weight(w, dtype, cout_tiles=3)
+        pw = K.pack_conv_weight_ws(w, cout_tiles=9)
+        for name, p, deep in (("ksplit", pk, 2), ("ws", pw, 3)):
+            for _ in range(reps):
+                K.conv_forward([x], p, b, N, H, W, act=hip.ACT_RELU, out=out, deep=deep)
+            for _ in range(reps):
+                K.conv_forward([x], p, b, N, H, W, alpha=0.1, res=r, out=out, deep=deep)
+            torch.cuda.synchronize()
     print("done")
 
 

@@ -7,9 +7,11 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libvmg_hip.so")
+DIAG = os.environ.get("VMG_DIAG") == "1"  # diagnostics build (in-kernel stamps, ablation bits): a library of its own, never the shipped one
+LIB = os.path.join(HERE, "libvmg_hip_diag.so" if DIAG else "libvmg_hip.so")
+OBJDIR = os.path.join(HERE, "build_diag" if DIAG else "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wshadow", "-Werror=shadow"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wshadow", "-Werror=shadow"] + (["-DVMG_DIAG"] if DIAG else [])
 
 
 def sources():
@@ -29,9 +31,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(
                 os.path.getmtime(src), *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))),

@@ -71,6 +71,7 @@ struct ConvK {
   int actgrad, ps;
   int nstages;     // total stages over all sources
   int halo_bytes;  // LDS bytes reserved for the halo tile
+  int ring;        // weight-streaming kernel: LDS ring slots (4 when they fit beside the halo tile, else 3)
   int vec8;        // 1: out / res / aux / out_pre rows are 16-byte aligned with strides % 8 == 0, Cout % 16 == 0, no PixelShuffle
   unsigned long long* stamps;  // diagnostics: per-wave s_memrealtime stamps (8 per wave) when non-null (vmg_conv_debug_stamps)
   int dbg;         // ablation bits (env VMG_CONV_DBG, diagnostics only): 1 no weight DMA, 4 no halo staging, 8 no store, 16 return at once, 32 no main loop, 128 no XCD-aware tile order
@@ -873,6 +874,418 @@ __global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int 
   }
 }
 
+// ================================================================================================ weight-streaming variant
+// conv_ws_kernel: bf16 3x3, ONE workgroup per 128-pixel tile (8 rows x 16 columns) and per block of NCT*16 output channels
+// (144 or 112: all of them for the convs of the recurrent chains), seven waves with fixed roles:
+//   * waves 4..6 are LOADERS: they copy the halo tile (10 x 18 pixels, all channels of a source block) and then stream the
+//     packed weights through a 3-slot LDS ring by LDS-DMA, one stage (= 3 k-steps = 3*NCT KiB; loader wave l copies k-step l)
+//     per barrier interval, one stage ahead of the one being consumed, with COUNTED s_waitcnt vmcnt;
+//   * waves 0..3 are CONSUMERS, one per SIMD: wave w accumulates pixel rows 2w, 2w+1 x all NCT channel tiles (2*NCT MFMAs per
+//     k-step from 2 activation + NCT weight fragments read from LDS, three static fragment sets, reads one k-step ahead,
+//     the last k-step of a stage multiplied AFTER the stage barrier so that the first reads of the next stage are covered).
+// Why: the K-split kernel above gives every 64-pixel x 48-channel workgroup its own copy of a third of the weights (124 KiB) and
+// of the halo (31 KiB) -- 238 MB through L2 -> CU per launch at M = 32 768, which is what bounds it (MFMA 23 % busy).  Here a CU
+// pulls the 373 KiB of weights ONCE for 128 pixels x 144 channels: 108 MB per launch, 256 workgroups = one per CU.
+// K order per source block of CH 8-channel chunks: for each full 32-channel block: 9 taps (one tap per k-step, lane group g =
+// chunk 4*blk + g); then the remainder chunks R = CH % 4, several TAPS per k-step (R = 2: lane groups 0,1 = tap 2j, groups
+// 2,3 = tap 2j+1), so that 144 channels cost 42 k-steps instead of 45.  ws_slot() below is the single definition of that
+// order for the packer and the kernel.
+template <int NCT>
+struct WsGeo {
+  static constexpr int COB = NCT * 16;
+  static constexpr int KSB = COB * 64;  // bytes of one k-step image [4 lane groups][COB][8] bf16 = NCT KiB
+  static constexpr int STG = 3 * KSB;   // a stage = 3 k-steps
+  static constexpr int TH = 8, TWH = 18, THH = 10;
+  static constexpr int NLW = 3;         // loader waves
+  static constexpr int THREADS = (4 + NLW) * 64;
+  static constexpr int NIT = EpiLds<NCT>::NIT;
+};
+__host__ __device__ inline int ws_rem_ksteps(int R) { return R == 0 ? 0 : (R == 1 ? 3 : (R == 2 ? 6 : 9)); }
+__host__ __device__ inline int ws_ksteps(int CH) { return 9 * (CH / 4) + ws_rem_ksteps(CH % 4); }  // always a multiple of 3
+// (tap, chunk) of lane group g in k-step j of a block of CH chunks; tap = -1: empty slot (zero weights)
+__host__ __device__ inline void ws_slot(int CH, int j, int g, int& tap, int& chunk) {
+  const int nfull = CH / 4, R = CH % 4;
+  if (j < 9 * nfull) { tap = j % 9; chunk = 4 * (j / 9) + g; return; }
+  const int jr = j - 9 * nfull;
+  if (R == 1) { tap = 4 * jr + g; chunk = 4 * nfull; }
+  else if (R == 2) { tap = 2 * jr + (g >> 1); chunk = 4 * nfull + (g & 1); }
+  else { tap = (g == 3) ? -1 : jr; chunk = 4 * nfull + (g == 3 ? 0 : g); }
+  if (tap > 8) tap = -1;
+}
+
+// diagnostics build only: stamp slot `slot` (0..31) of wave `wave` of this workgroup (100 MHz clock)
+__device__ __forceinline__ void ws_stamp(const ConvK& a, int wave, int slot) {
+#ifdef VMG_DIAG
+  if (a.stamps && slot < 32) {
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 32 + slot] = t;
+  }
+#endif
+}
+
+// The epilogue works on ITEMS = (pixel of the tile, 8 consecutive output channels): item j = pixel j / C8, channel group j % C8,
+// thread `tid` of the 448 owns items tid, tid + 448, ...  The consumers spill their accumulators to an LDS patch [128 pixels][COB]
+// fp32 (pixel stride COB*4 + 16 bytes: conflict-free 16-byte writes), then ALL seven waves turn items into 16-byte global
+// stores -- whole 288-byte pixel rows leave as contiguous runs.  The residual (or, without one, the activation-gradient) operand
+// of a thread's items is fetched at kernel start, so its latency is hidden by the main loop.
+template <int NCT>
+struct WsItems {
+  static constexpr int C8 = 2 * NCT, TOTAL = 128 * C8, THREADS = WsGeo<NCT>::THREADS, NIT = (TOTAL + THREADS - 1) / THREADS;
+  static constexpr int PSTR = NCT * 64 + 16;  // bytes per pixel in the patch
+  __device__ static __forceinline__ void decode(int j, int& pxl, int& c8) {
+    pxl = NCT == 9 ? (j * 3641) >> 16 : (j * 4682) >> 16;  // j / 18, j / 14 (exact for j < 4000)
+    c8 = j - pxl * C8;
+  }
+};
+
+template <int NCT>
+__global__ __launch_bounds__(WsGeo<NCT>::THREADS, 2) void conv_ws_kernel(const ConvK a) {
+  using G = WsGeo<NCT>;
+  using I = WsItems<NCT>;
+  using T = bf16;
+  constexpr int COB = G::COB, KSB = G::KSB, STG = G::STG;
+  static_assert(128 * I::PSTR <= 3 * STG, "the epilogue patch must fit the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* ring = smem + a.halo_bytes;
+  const int R = a.ring;  // 4 slots: a slot is refilled two barriers after its last read, no wait needed; 3: one barrier, explicit wait
+  float* lbias = reinterpret_cast<float*>(ring + R * STG);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = blockIdx.y;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, 0);
+  const int tx = bid % a.tiles_x;
+  const int rr = bid / a.tiles_x;
+  const int ty = rr % a.tiles_y, n = rr / a.tiles_y;
+  const int nstages = a.nstages;
+  ws_stamp(a, wave, 0);
+
+  // ---- every wave: its share of the first halo tile (instruction q of the [row][pixel][vector] list goes to wave q % 7)
+  auto issue_halo = [&](int s, int first, int step, auto hidden) {
+    constexpr bool HIDDEN = decltype(hidden)::value;
+    const int ch = a.src_ch[s];
+    const char* sp = a.src[s];
+    const int ps32 = (int)(a.src_ps[s] * 2);
+    const int vpp = ch >> 3, row_vecs = G::TWH * vpp, total = G::THH * row_vecs;
+    const float inv_row = 1.0f / (float)row_vecs, inv_vpp = 1.0f / (float)vpp;
+    const int y0 = ty * G::TH - 1, x0 = tx * 16 - 1;
+    const char* origin = sp + (((long long)n * a.H + y0) * a.W + x0) * (long long)ps32;
+    const int rowstep = a.W * ps32;
+    const int nq = a.halo_bytes >> 10;
+    for (int q = first; q < nq; q += step) {
+      const int L = q * 64 + lane;
+      const int r = (int)(((float)L + 0.5f) * inv_row);  // exact: L < 2^16
+      const int rem = L - r * row_vecs;
+      const int p = (int)(((float)rem + 0.5f) * inv_vpp);
+      const int v = rem - p * vpp;
+      const bool ok = (L < total) & ((unsigned)(y0 + r) < (unsigned)a.H) & ((unsigned)(x0 + p) < (unsigned)a.W);
+      const long long off = ok ? (long long)(r * rowstep + p * ps32 + v * 16) : (reinterpret_cast<const char*>(&g_conv_zero16) - origin);
+      if (HIDDEN) {
+        // consumer waves: the LDS-DMA is an asm statement, so that hipcc does not know this wave has written LDS behind its back
+        // -- with the builtin it treats every later ds_read as possibly aliasing and waits lgkmcnt(0) in front of each MFMA
+        // group (measured: 0.72 us per stage instead of 0.45).  M0 is saved and restored inside the statement; the copies are
+        // counted by hand (the s_waitcnt before B_0).
+        unsigned keep;
+        const char* gp = origin + off;
+        const unsigned ldst = (unsigned)(uintptr_t)LDS_PTR(halo + q * 1024);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+      } else {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(origin + off), LDS_PTR(halo + q * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- every thread: the epilogue operand of its items (residual, else activation-gradient operand), fetched now
+  const bf16* esrc = reinterpret_cast<const bf16*>(a.res ? a.res : a.aux);
+  const long long eps = a.res ? a.res_ps : a.aux_ps;
+  const long long tile_pix = ((long long)n * a.H + ty * G::TH) * a.W + tx * 16;
+  bf16x8 pre[I::NIT];
+  auto prefetch = [&]() {
+    if (!esrc) return;
+    const bf16* ebase = esrc + tile_pix * eps + cb * COB;
+#pragma unroll
+    for (int it = 0; it < I::NIT; ++it) {
+      int pxl, c8;
+      I::decode(it * I::THREADS + tid, pxl, c8);
+      const int row = pxl >> 4, col = pxl & 15;
+      const bool valid = (pxl < 128) & (ty * G::TH + row < a.H) & (tx * 16 + col < a.W) & (cb * COB + c8 * 8 < a.Cout);
+      const int off = valid ? (row * a.W + col) * (int)eps + c8 * 8 : 0;  // (invalid items read the tile's first vector: always in range)
+      pre[it] = *reinterpret_cast<const bf16x8*>(ebase + off);
+    }
+  };
+
+  // Every workgroup walks the stages of a source in its own ROTATED order (first stage = bid % stages; the sum is order-free),
+  // and a loader copies the pieces of its k-step in a rotated order too: neighbouring CUs do not ask the L2 for the same lines at
+  // the same moment.
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    const int lw = wave - 4;
+    const char* wsrc = a.wpack + ((long long)cb * nstages) * STG + lw * KSB + lane * 16;
+    const int prot = bid % NCT;
+    int slot_i = 0;  // ring slot of the next stage to issue
+    int issued = 0;
+    // issue cursor: source, first stage of the source, its stage count, rotated stage index within it
+    int is = 0, ist0 = 0, inst = a.src_nst[0], isl = 0, irot = bid % a.src_nst[0];
+    auto issue_stage = [&]() {
+      const char* gsrc = wsrc + (long long)(ist0 + irot) * STG;
+      char* dst = ring + slot_i * STG + lw * KSB;
+#pragma unroll
+      for (int i = 0; i < NCT; ++i) {
+        int ii = i + prot;
+        ii = ii >= NCT ? ii - NCT : ii;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + ii * 1024), LDS_PTR(dst + ii * 1024), 16, 0, 0);
+      }
+      ++issued;
+      slot_i = slot_i + 1 == R ? 0 : slot_i + 1;
+      irot = irot + 1 == inst ? 0 : irot + 1;
+      if (++isl == inst && issued < nstages) {
+        ++is;
+        ist0 += inst;
+        inst = a.src_nst[is];
+        isl = 0;
+        irot = bid % inst;
+      }
+    };
+    {
+      const int c = tid - 256;  // the block's bias goes to LDS (read by the consumers behind B_0)
+      if (c < COB) lbias[c] = (a.bias && cb * COB + c < a.Cout) ? a.bias[cb * COB + c] : 0.f;
+    }
+    prefetch();  // oldest in the queue: never counted by the waits below
+    asm volatile("" ::: "memory");
+    issue_stage();  // (the consumers, idle until B_0, copy the first halo tile)
+    issue_stage();  // (every source has >= 3 stages)
+    ws_stamp(a, wave, 1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NCT) : "memory");  // stage 0 has landed (stage 1 may be in flight), the bias is written
+    ws_stamp(a, wave, 2);
+    __builtin_amdgcn_s_barrier();  // B_0
+    int t = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+      const int nst = a.src_nst[s];
+      for (int sl = 0; sl < nst; ++sl, ++t) {
+        // just behind B_t: the consumers have finished stage t-1, its slot takes stage t+2
+        if (issued < nstages) issue_stage();
+        const bool last = t + 1 == nstages, sw = !last && sl + 1 == nst;
+        if (sw) {
+          __builtin_amdgcn_s_barrier();  // X: the consumers are done with the halo tile of source s
+          issue_halo(s + 1, lw, G::NLW, std::false_type{});
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (last || issued == nstages) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCT) : "memory");  // stage t+1 has landed; stage t+2 stays in flight
+        }
+        ws_stamp(a, wave, 4 + t);      // the loader is ready for B_{t+1}
+        __builtin_amdgcn_s_barrier();  // B_{t+1}, or E behind the last stage
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ consumer waves
+    const int px = lane & 15, g = lane >> 4;
+    issue_halo(0, wave, 4, std::true_type{});
+    asm volatile("" ::: "memory");  // the operand loads below stay YOUNGER than the halo pieces: the counted wait before B_0 relies on it
+    prefetch();
+
+    f32x4 acc[NCT][2];
+    Frag<T> wf[3][NCT], xf[3][2];
+
+    // cursor over (source, stage of the source); csl counts the stages done, crot is the rotated stage index being consumed
+    int cs = 0, csl = 0, cnst = a.src_nst[0], crot = bid % cnst;
+    int CH = a.src_ch[0] >> 3, nfull3 = 3 * (CH >> 2), pixb = a.src_pixb[0], rowb = G::TWH * pixb;
+    const char* xb = halo + ((2 * wave) * G::TWH + px) * pixb;
+    int slot = 0;
+    int xo[3];
+    auto stage_offsets = [&]() {
+      if (crot < nfull3) {
+        const int cbk = (crot * 171) >> 9, ky = crot - 3 * cbk;  // crot / 3, crot % 3 (exact below 512)
+        const int base = ky * rowb + cbk * 64 + g * 16;
+        xo[0] = base; xo[1] = base + pixb; xo[2] = base + 2 * pixb;
+      } else {  // remainder chunks (CH % 4 == 2: the host admits 0 and 2 only): lane groups 0,1 = tap 2j, groups 2,3 = tap 2j + 1
+        const int nfull = CH >> 2, jr0 = 3 * (crot - nfull3);
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          int tap = 2 * (jr0 + jj) + (g >> 1);
+          tap = tap > 8 ? 8 : tap;          // empty slots carry zero weights: any valid address
+          const int tyy = (tap * 11) >> 5;   // tap / 3 for 0..8
+          xo[jj] = tyy * rowb + (tap - 3 * tyy) * pixb + (4 * nfull + (g & 1)) * 16;
+        }
+      }
+    };
+    auto advance = [&]() {  // to the next stage (same source)
+      ++csl;
+      crot = crot + 1 == cnst ? 0 : crot + 1;
+      slot = slot + 1 == R ? 0 : slot + 1;
+    };
+    auto next_source = [&]() {
+      ++cs;
+      csl = 0; cnst = a.src_nst[cs]; crot = bid % cnst;
+      CH = a.src_ch[cs] >> 3; nfull3 = 3 * (CH >> 2); pixb = a.src_pixb[cs]; rowb = G::TWH * pixb;
+      xb = halo + ((2 * wave) * G::TWH + px) * pixb;
+      slot = slot + 1 == R ? 0 : slot + 1;
+    };
+    auto rd = [&](int set, int jj) {
+      // activation fragments first: LDS reads return in order, so the first MFMA of the next k-step waits for 3 of the 11
+      // reads only and the later ones have its predecessors as cover
+      xf[set][0].load(xb + xo[jj]);
+      xf[set][1].load(xb + rowb + xo[jj]);
+      const char* wp = ring + slot * STG + jj * KSB + g * (COB * 16) + px * 16;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) wf[set][ct].load(wp + ct * 256);
+    };
+    auto mm = [&](int set) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        acc[ct][0] = mma(wf[set][ct], xf[set][0], acc[ct][0]);
+        acc[ct][1] = mma(wf[set][ct], xf[set][1], acc[ct][1]);
+      }
+    };
+    // one phase = the MFMAs of one k-step with the fragment reads of the next one slotted into the gaps between them (an MFMA
+    // holds the SIMD's issue port for half of its 16 cycles: one LDS read per gap is free), fenced so that hipcc neither starts
+    // the next k-step's MFMAs early nor bunches the reads.  Measured per stage (3 k-steps, 54 MFMAs per wave; 0.54 us would be
+    // the matrix pipe alone at the ~1.6 GHz the chip holds under this load): reads bunched in front of the MFMAs 0.92 us,
+    // interleaved 0.70 us.
+    auto phase_fence = [&]() {
+#pragma unroll
+      for (int i = 0; i < NCT + 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCT - (NCT + 2), 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (esrc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(I::NIT) : "memory");  // this wave's halo share has landed; the operand prefetch may fly on
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws_stamp(a, wave, 1);
+    __builtin_amdgcn_s_barrier();  // B_0: halo and the first stage are in LDS
+    asm volatile("" ::: "memory");
+    ws_stamp(a, wave, 2);
+    // the accumulators start from the bias (a lane holds output channels ct*16 + 4g .. +3 of its pixels)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + ct * 16 + g * 4);
+      acc[ct][0] = bv;
+      acc[ct][1] = bv;
+    }
+    stage_offsets();
+    rd(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+      for (int sl = 0; sl + 1 < cnst; ++sl, ++t) {  // every stage of the source but its last: one straight-line body
+        rd(1, 1);
+        mm(0);
+        phase_fence();
+        rd(2, 2);
+        mm(1);
+        phase_fence();
+        if (R == 3) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) (a builtin: hipcc's wait bookkeeping sees it): with 3 slots the
+                                                         // loaders refill stage t's slot right behind the barrier
+        ws_stamp(a, wave, 3 + t);                        // the consumer is ready for B_{t+1}
+        __builtin_amdgcn_s_barrier();        // B_{t+1}
+        asm volatile("" ::: "memory");
+        advance();
+        stage_offsets();
+        rd(0, 0);
+        mm(2);
+        phase_fence();
+      }
+      // the last stage of the source
+      rd(1, 1);
+      mm(0);
+      phase_fence();
+      rd(2, 2);
+      mm(1);
+      phase_fence();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      ws_stamp(a, wave, 3 + t);
+      __builtin_amdgcn_s_barrier();  // X: done with this source's halo tile (the loaders bring the next one) / E behind the last stage
+      asm volatile("" ::: "memory");
+      mm(2);
+      __builtin_amdgcn_sched_barrier(0);
+      ++t;
+      if (s + 1 < a.nsrc) {
+        __builtin_amdgcn_s_barrier();  // B_{t}: the next source's halo tile has landed
+        asm volatile("" ::: "memory");
+        next_source();
+        stage_offsets();
+        rd(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    ws_stamp(a, wave, 28);
+    // accumulators -> patch (the ring is idle: every consumer is past E, the loaders have nothing in flight)
+    char* prow = ring + ((2 * wave) * 16 + px) * I::PSTR + g * 16;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      *reinterpret_cast<f32x4*>(prow + ct * 64) = acc[ct][0];
+      *reinterpret_cast<f32x4*>(prow + 16 * I::PSTR + ct * 64) = acc[ct][1];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+  ws_stamp(a, wave, 29);
+  __builtin_amdgcn_s_barrier();  // F: the patch is complete
+  asm volatile("" ::: "memory");
+
+  // ---- items -> global memory, all seven waves
+  {
+    bf16* out = reinterpret_cast<bf16*>(a.out) + tile_pix * a.out_ps + cb * COB;
+    bf16* out_pre = a.out_pre ? reinterpret_cast<bf16*>(a.out_pre) + tile_pix * a.out_ps + cb * COB : nullptr;
+    const bf16* auxb = a.aux ? reinterpret_cast<const bf16*>(a.aux) + tile_pix * a.aux_ps + cb * COB : nullptr;
+#pragma unroll
+    for (int it = 0; it < I::NIT; ++it) {
+      int pxl, c8;
+      I::decode(it * I::THREADS + tid, pxl, c8);
+      const int row = pxl >> 4, col = pxl & 15;
+      const bool valid = (pxl < 128) & (ty * G::TH + row < a.H) & (tx * 16 + col < a.W) & (cb * COB + c8 * 8 < a.Cout);
+      if (!valid) continue;
+      const char* pp = ring + pxl * I::PSTR + c8 * 32;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(pp), hi = *reinterpret_cast<const f32x4*>(pp + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};  // (bias included: the accumulators started from it)
+      const int opix = row * a.W + col;
+      if (out_pre) {
+        bf16x8 tq;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tq[r] = (bf16)v[r];
+        *reinterpret_cast<bf16x8*>(out_pre + opix * (int)a.out_ps + c8 * 8) = tq;
+      }
+      // wave-uniform branches: each activation costs only what it needs (ReLU: one max per element)
+      if (a.act == VMG_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+      } else if (a.act == VMG_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (a.act == VMG_ACT_LRELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+      }
+      if (a.alpha != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= a.alpha;
+      }
+      if (auxb) {
+        bf16x8 u = pre[it];
+        if (a.res) u = *reinterpret_cast<const bf16x8*>(auxb + opix * (int)a.aux_ps + c8 * 8);  // both operands: aux is read here
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float uf = (float)u[r];
+          v[r] *= a.actgrad == 3 ? gelu_erf_grad(uf) : (uf > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+        }
+      }
+      if (a.res) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)pre[it][r];
+      }
+      bf16x8 tq;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tq[r] = (bf16)v[r];
+      *reinterpret_cast<bf16x8*>(out + opix * (int)a.out_ps + c8 * 8) = tq;
+    }
+  }
+  ws_stamp(a, wave, 31);
+}
+
 // ------------------------------------------------------------------------------------------- packing
 struct PackK {
   const float* w;
@@ -916,6 +1329,35 @@ __global__ void conv_pack_kernel(const PackK p) {
       }
     }
     reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
+  }
+}
+
+// weight-streaming layout: [cout block][stage][k-step jj 0..2][lane group g][co][8] bf16, K slots by ws_slot()
+__global__ void convws_pack_kernel(const PackK p) {
+  const int KSE = 4 * p.cob * 8;  // elements per k-step
+  const long long total = (long long)p.ncb * p.nstages * 3 * KSE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    long long t = i >> 3;
+    const int co = (int)(t % p.cob); t /= p.cob;
+    const int g = (int)(t & 3); t >>= 2;
+    const int jj = (int)(t % 3); t /= 3;
+    const int stage = (int)(t % p.nstages);
+    const int cb = (int)(t / p.nstages);
+    int s = 0;
+    while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
+    const int j = (stage - p.src_st0[s]) * 3 + jj;
+    int tap, chunk;
+    ws_slot(p.src_ch[s] >> 3, j, g, tap, chunk);
+    const int col = cb * p.cob + co;
+    float v = 0.f;
+    if (tap >= 0 && col < p.on) {
+      const int kc = p.src_off[s] + chunk * 8 + e;
+      const int oc = p.o0 + col;
+      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * 9 + tap];
+      else v = p.w[((long long)kc * p.I + oc) * 9 + (8 - tap)];
+    }
+    reinterpret_cast<bf16*>(p.out)[i] = (bf16)v;
   }
 }
 
@@ -1061,6 +1503,29 @@ int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
   return 0;
 }
 
+template <int NCT>
+int launch_ws(const ConvK& k, int ncb, hipStream_t st) {
+  using G = WsGeo<NCT>;
+  ConvK kk = k;
+  kk.ring = (k.halo_bytes + 4 * G::STG + G::COB * 4 <= 160 * 1024) ? 4 : 3;
+  const int lds = k.halo_bytes + kk.ring * G::STG + G::COB * 4;
+  VMG_CHECK(lds <= 160 * 1024, "conv (weight-streaming): LDS request %d B exceeds 160 KiB", lds);
+  auto fn = conv_ws_kernel<NCT>;
+  static bool attr_set[VMG_MAX_DEVICES] = {};
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = true;
+  }
+  const long long nblk = (long long)k.N * k.tiles_y * k.tiles_x;
+  VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
+  const bool prof = (k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(G::THREADS), lds, st, kk);
+  if (prof) vmg_prof_after(st);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 #ifdef VMG_DIAG
@@ -1116,6 +1581,49 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ws_plan(int nsrc, const int* src_off, const int* src_ch, PackK& p) {
+  const int n = expand_sources(nsrc, src_off, src_ch, p.src_off, p.src_ch, nullptr);
+  if (n <= 0) return -1;
+  int st = 0;
+  for (int s = 0; s < n; ++s) {
+    p.src_st0[s] = (short)st;
+    p.src_nst[s] = (short)(ws_ksteps(p.src_ch[s] >> 3) / 3);
+    st += p.src_nst[s];
+  }
+  p.nsrc = n;
+  p.nstages = st;
+  return n;
+}
+
+extern "C" int64_t vmg_convws_pack_bytes(int on, int nsrc, const int* src_ch, int cout_tiles) {
+  PackK p;
+  memset(&p, 0, sizeof(p));
+  if (cout_tiles <= 0 || cout_tiles > 9 || on <= 0 || nsrc < 1 || nsrc > 4 || ws_plan(nsrc, nullptr, src_ch, p) <= 0) return -1;
+  const int cob = cout_tiles * 16;
+  return (int64_t)cdiv(on, cob) * p.nstages * 3 * (int64_t)cob * 64;
+}
+
+extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch,
+                               int transpose_flip, int cout_tiles, void* packed, void* stream) {
+  VMG_CHECK(w && packed, "convws_pack: null pointer");
+  VMG_CHECK(cout_tiles == 7 || cout_tiles == 9, "convws_pack: cout_tiles must be 7 or 9");
+  VMG_CHECK(nsrc >= 1 && nsrc <= 4, "convws_pack: nsrc must be 1..4");
+  VMG_CHECK(!transpose_flip || nsrc == 1, "convws_pack: data-gradient packing takes one K slice");
+  PackK p;
+  memset(&p, 0, sizeof(p));
+  VMG_CHECK(ws_plan(nsrc, src_off, src_ch, p) > 0, "convws_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
+  const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
+  for (int s = 0; s < p.nsrc; ++s) VMG_CHECK(p.src_off[s] >= 0 && p.src_off[s] + p.src_ch[s] <= kdim, "convws_pack: K slice out of range");
+  VMG_CHECK(o0 >= 0 && on > 0 && o0 + on <= odim, "convws_pack: output slice out of range");
+  p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = 3; p.o0 = o0; p.on = on; p.transpose_flip = transpose_flip;
+  p.cob = cout_tiles * 16; p.ncb = cdiv(on, p.cob);
+  const long long total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(convws_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   VMG_LAUNCH_CHECK();
   return 0;
 }
@@ -1182,6 +1690,23 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   k.nstages = kt; k.halo_bytes = (halo + 1023) & ~1023;  // the LDS-DMA copy writes whole 1-KiB pieces
   VMG_CHECK(d->out_ps >= (d->pixel_shuffle ? d->Cout / 4 : d->Cout), "conv_fwd: out pixel stride too small");
   hipStream_t st = (hipStream_t)stream;
+  if (d->deep == 3) {
+    // weight-streaming kernel: 8 x 16 pixel tiles, dense halo, its own packed layout (vmg_convws_pack)
+    VMG_CHECK(d->dtype == VMG_BF16 && d->ks == 3 && k.vec8 && (ntb == 7 || ntb == 9), "conv_fwd: the weight-streaming kernel is bf16 3x3 with 16-byte aligned rows, cout_tiles 7 or 9");
+    for (int s = 0; s < n; ++s) VMG_CHECK(k.src_ch[s] % 16 == 0, "conv_fwd: the weight-streaming kernel takes channel blocks that are multiples of 16 (got %d)", k.src_ch[s]);
+    int kt3 = 0, halo3 = 0;
+    for (int s = 0; s < n; ++s) {
+      k.src_pixb[s] = k.src_ch[s] * 2;
+      k.src_nst[s] = (short)(ws_ksteps(k.src_ch[s] >> 3) / 3);
+      kt3 += k.src_nst[s];
+      const int hb = 10 * 18 * k.src_pixb[s];
+      if (hb > halo3) halo3 = hb;
+    }
+    k.nstages = kt3;
+    k.halo_bytes = (halo3 + 1023) & ~1023;  // whole 1-KiB LDS-DMA pieces
+    k.tiles_y = cdiv(d->H, 8);
+    return ntb == 9 ? launch_ws<9>(k, ncb, st) : launch_ws<7>(k, ncb, st);
+  }
   if (d->deep == 4 && d->dtype == VMG_BF16 && d->ks == 1 && n == 1 && k.src_ch[0] <= 160 && k.src_pixb[0] == k.src_ch[0] * 2 && k.vec8 &&
       (ntb == 3 || ntb == 5)) {
     // (a hint: anything it does not cover -- padded LDS stride, several sources, unaligned rows -- takes the general kernel below)

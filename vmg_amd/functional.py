@@ -24,17 +24,23 @@ def _pad_to(n: int, m: int = 8) -> int:
     return (n + m - 1) // m * m
 
 
-def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None):
+def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None, pixel_shuffle: bool = False):
     """(cout_tiles, mt, deep) for a conv over M pixels.  Measured on MI355X (tools/bench_conv.py under rocprofv3, kernel
     durations): the 144-channel 3x3 convs run best on the K-split kernel (deep = 2) as 64-pixel x 48-channel workgroups
     (three cout blocks, no padded tile, 138 registers -> three workgroups per CU): 25 us at M = 32 768 (27 us with two
     blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
+    if USE_WS and src_ch is not None and not pixel_shuffle:
+        t = K.ws_eligible(cout, ks, dtype, src_ch)
+        if t:
+            return t, 1, 3  # weight-streaming kernel: 128-pixel x 144/112-channel workgroups, the CU pulls the weights once
     if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
         return 3, 1, 2  # 288 (local_cnn): 151 us vs 247 us at 144 -> 288, M = 114 688; the 576-channel PixelShuffle convs were slower this way
     if dtype == torch.bfloat16 and ks == 1 and cout == 144 and src_ch is not None and len(src_ch) == 1 and src_ch[0] == 144 and M >= 65536:
         return 5, 1, 4  # the 144 -> 144 Linears of stage 0 (token mixers, proj): wave-autonomous kernel, 21 us vs 33 us at M = 114 688 (no gain at M = 32 768)
     return None, 1, 0
 
+
+USE_WS = True  # route eligible bf16 3x3 convs to the weight-streaming kernel (tests flip it to compare both)
 
 _WEIGHT_EPOCH = [0]
 
@@ -46,10 +52,10 @@ def bump_weight_epoch():
 
 
 def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
-           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None) -> K.PackedConv:
+           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None, deep: int = 0) -> K.PackedConv:
     """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
     needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8)."""
-    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles)
+    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles, deep == 3)
     ver = (weight._version, _WEIGHT_EPOCH[0])
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
@@ -74,12 +80,18 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
                 off += c
             w = torch.cat(parts, 1)
             src_ch = [_pad_to(c) for c in src_ch]
-        pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles)
+        if deep == 3:
+            pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles)
+        else:
+            pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles)
     elif kind == "dgrad":
         on = I - i0 if on is None else on
         if O % 8:
             w = torch.cat([w, w.new_zeros(_pad_to(O) - O, *w.shape[1:])], 0)
-        pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
+        if deep == 3:
+            pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
+        else:
+            pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
     else:
         raise HipError(kind)
     _PACK_CACHE[key] = (ver, pw, weight)
@@ -236,8 +248,8 @@ class _Conv2d(torch.autograd.Function):
         dt = srcs[0].dtype
         src_ch = [s.shape[-1] for s in srcs]
         srcs_p = [_pad_channels(s) for s in srcs]
-        tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt, src_ch)
-        pw = packed(weight, dt, "fwd", src_ch, tiles=tiles)
+        tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt, src_ch, pixel_shuffle)
+        pw = packed(weight, dt, "fwd", src_ch, tiles=tiles, deep=deep)
         need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
         out, pre = K.conv_forward(srcs_p, pw, bias, N, H, W, act=act, slope=slope, alpha=alpha, res=res,
                                   pixel_shuffle=pixel_shuffle, want_pre=need_pre, mt=mt, deep=deep)
@@ -280,7 +292,7 @@ class _Conv2d(torch.autograd.Function):
         for i, c in enumerate(ctx.src_ch):
             if ctx.needs_input_grad[4 + i]:
                 tiles, mt, deep = choose_tiling(N * H * W, c, ks, dpre.dtype, [weight.shape[0]])
-                pw = packed(weight, dpre.dtype, "dgrad", None, off, c, tiles=tiles)
+                pw = packed(weight, dpre.dtype, "dgrad", None, off, c, tiles=tiles, deep=deep)
                 dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep)
                 d_srcs.append(dx.reshape(ctx.src_shapes[i]))
             else:
@@ -324,13 +336,14 @@ class _ResidualChain(torch.autograd.Function):
         src_ch = [t.shape[-1] for t in srcs]
         w0, b0 = params[0], params[1]
         C = w0.shape[0]
-        tiles, mt, deep = choose_tiling(M, C, 3, dt)
-        y, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=tiles), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=mt, deep=deep)
+        t0_, m0_, d0_ = choose_tiling(M, C, 3, dt, src_ch)
+        y, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=m0_, deep=d0_)
+        tiles, mt, deep = choose_tiling(M, C, 3, dt, [C])
         saved = [y]
         for k in range(nblk):
             w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
-            t, _ = K.conv_forward([y], packed(w1, dt, "fwd", [C], tiles=tiles), b1, N, H, W, act=hip.ACT_RELU, mt=mt, deep=deep)
-            y, _ = K.conv_forward([t], packed(w2, dt, "fwd", [C], tiles=tiles), b2, N, H, W, alpha=r_scaling, res=y, mt=mt, deep=deep)
+            t, _ = K.conv_forward([y], packed(w1, dt, "fwd", [C], tiles=tiles, deep=deep), b1, N, H, W, act=hip.ACT_RELU, mt=mt, deep=deep)
+            y, _ = K.conv_forward([t], packed(w2, dt, "fwd", [C], tiles=tiles, deep=deep), b2, N, H, W, alpha=r_scaling, res=y, mt=mt, deep=deep)
             saved += [t, y]
         ctx.meta = (r_scaling, nsrc, nblk, N, H, W, src_ch, C)
         ctx.wgrad = any(ctx.needs_input_grad[2 + nsrc:])
@@ -351,13 +364,13 @@ class _ResidualChain(torch.autograd.Function):
         g = g.contiguous()
         dt = g.dtype
         M = N * H * W
-        tiles, mt, deep = choose_tiling(M, C, 3, dt)
+        tiles, mt, deep = choose_tiling(M, C, 3, dt, [C])
         pg = [None] * len(params)  # parameter gradients returned through autograd (mode 'autograd')
         for k in range(nblk - 1, -1, -1):
             w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
             yk, tk = saved[2 * k], saved[2 * k + 1]
             # d t_k = r * dgrad2(g) masked by relu'(t_k)
-            dt_k, _ = K.conv_forward([g], packed(w2, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, alpha=r, aux=tk, actgrad=1, mt=mt, deep=deep)
+            dt_k, _ = K.conv_forward([g], packed(w2, dt, "dgrad", None, 0, C, tiles=tiles, deep=deep), None, N, H, W, alpha=r, aux=tk, actgrad=1, mt=mt, deep=deep)
             if ctx.defer:
                 DEFERRED.add(w2, b2, [tk], [C], g, 3, N, H, W, scale=r, gen=ctx.gen)
                 DEFERRED.add(w1, b1, [yk], [C], dt_k, 3, N, H, W, gen=ctx.gen)
@@ -365,15 +378,15 @@ class _ResidualChain(torch.autograd.Function):
                 pg[4 + 4 * k], pg[5 + 4 * k] = _wgrad_now(w2, True, [tk], [C], g, 3, N, H, W, scale=r)
                 pg[2 + 4 * k], pg[3 + 4 * k] = _wgrad_now(w1, True, [yk], [C], dt_k, 3, N, H, W)
             # d y_k = g + dgrad1(d t_k)
-            g, _ = K.conv_forward([dt_k], packed(w1, dt, "dgrad", None, 0, C, tiles=tiles), None, N, H, W, res=g, mt=mt, deep=deep)
+            g, _ = K.conv_forward([dt_k], packed(w1, dt, "dgrad", None, 0, C, tiles=tiles, deep=deep), None, N, H, W, res=g, mt=mt, deep=deep)
         w0, b0 = params[0], params[1]
         dpre0 = K.act_backward(g, saved[0], hip.ACT_LRELU, 0.1, 1.0)
         d_srcs = []
         off = 0
         for i, c in enumerate(src_ch):
             if ctx.needs_input_grad[2 + i]:
-                t_, m_, d_ = choose_tiling(M, c, 3, dt)
-                dx, _ = K.conv_forward([dpre0], packed(w0, dt, "dgrad", None, off, c, tiles=t_), None, N, H, W, mt=m_, deep=d_)
+                t_, m_, d_ = choose_tiling(M, c, 3, dt, [C])
+                dx, _ = K.conv_forward([dpre0], packed(w0, dt, "dgrad", None, off, c, tiles=t_, deep=d_), None, N, H, W, mt=m_, deep=d_)
                 d_srcs.append(dx)
             else:
                 d_srcs.append(None)

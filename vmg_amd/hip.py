@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvmg_hip.so")
+LIB_PATH = os.environ.get("VMG_HIP_LIB") or os.path.join(HERE, "libvmg_hip.so")  # VMG_HIP_LIB: the diagnostics build (tools/ only)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
@@ -47,6 +47,8 @@ SIGNATURES = {
     "vmg_conv_pack_bytes": (c_int64, [c_int, c_int, c_int, c_int, POINTER(c_int), c_int]),
     "vmg_conv_pack": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                               c_int, c_int, c_void_p, c_void_p]),
+    "vmg_convws_pack_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int]),
+    "vmg_convws_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_void_p, c_void_p]),
     "vmg_conv_fwd": (c_int, [POINTER(ConvDesc), c_void_p]),
     "vmg_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_void_p]),
     "vmg_pixel_shuffle": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

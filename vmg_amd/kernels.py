@@ -38,10 +38,11 @@ def cout_tiles_for(cout: int, dtype: torch.dtype = torch.bfloat16) -> int:
 class PackedConv:
     """Packed (device) weights of one convolution / linear for one direction (forward or data-gradient)."""
 
-    __slots__ = ("buf", "dtype", "ks", "cout", "src_ch", "cout_tiles")
+    __slots__ = ("buf", "dtype", "ks", "cout", "src_ch", "cout_tiles", "layout")
 
-    def __init__(self, buf, dtype, ks, cout, src_ch, cout_tiles):
+    def __init__(self, buf, dtype, ks, cout, src_ch, cout_tiles, layout="std"):
         self.buf, self.dtype, self.ks, self.cout, self.src_ch, self.cout_tiles = buf, dtype, ks, cout, list(src_ch), cout_tiles
+        self.layout = layout  # 'std': vmg_conv_pack; 'ws': vmg_convws_pack (the weight-streaming 3x3 kernel, deep = 3)
 
 
 def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None,
@@ -81,6 +82,53 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
     hip.check(l.vmg_conv_pack(code, w.data_ptr(), O, I, ks, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch),
                               1 if transpose_flip else 0, tiles, out.data_ptr(), hip.stream_ptr()), "vmg_conv_pack")
     return PackedConv(out, dtype, ks, on, src_ch, tiles)
+
+
+def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -> int:
+    """cout_tiles (9 or 7) if the weight-streaming kernel covers this conv (bf16, 3x3, output channels in blocks of 144 or 112,
+    source channel counts that split into blocks of <= 160 channels that are multiples of 16), else 0."""
+    if dtype != torch.bfloat16 or ks != 3:
+        return 0
+    for c in src_ch:
+        parts = 1
+        while c // parts > 160 or c % (8 * parts):
+            parts += 1
+            if parts > c // 8:
+                return 0
+        if (c // parts) % 16:
+            return 0
+    if cout % 144 == 0:
+        return 9
+    if cout % 112 == 0:
+        return 7
+    return 0
+
+
+def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None, src_off: Optional[Sequence[int]] = None, o0: int = 0,
+                        on: Optional[int] = None, transpose_flip: bool = False, cout_tiles: int = 9) -> PackedConv:
+    """bf16 pack of a 3x3 weight (O, I, 3, 3) for the weight-streaming kernel (same slicing conventions as pack_conv_weight)."""
+    hip.require_cuda(w)
+    if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        raise HipError("pack_conv_weight_ws expects a contiguous fp32 (O, I, 3, 3) weight")
+    O, I = w.shape[0], w.shape[1]
+    kdim, odim = (O, I) if transpose_flip else (I, O)
+    if src_ch is None:
+        src_ch, src_off = [kdim], [0]
+    if src_off is None:
+        src_off, acc = [], 0
+        for c in src_ch:
+            src_off.append(acc)
+            acc += c
+    if on is None:
+        on = odim - o0
+    l = hip.lib()
+    nbytes = l.vmg_convws_pack_bytes(on, len(src_ch), _intarr(src_ch), cout_tiles)
+    if nbytes <= 0:
+        raise HipError(f"vmg_convws_pack_bytes rejected channels {list(src_ch)} / cout_tiles {cout_tiles}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    hip.check(l.vmg_convws_pack(w.data_ptr(), O, I, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch), 1 if transpose_flip else 0,
+                                cout_tiles, out.data_ptr(), hip.stream_ptr()), "vmg_convws_pack")
+    return PackedConv(out, torch.bfloat16, 3, on, src_ch, cout_tiles, layout="ws")
 
 
 # vmg_conv_desc as one struct format (checked against the ctypes layout at import): field order of hip.ConvDesc
@@ -124,6 +172,8 @@ def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[to
         raise HipError(f"activation dtype {dt} != packed weight dtype {pw.dtype}")
     M = N * H * W
     nsrc = len(srcs)
+    if (pw.layout == "ws") != (deep == 3):
+        deep = 3 if pw.layout == "ws" else 0  # the packed layout decides the kernel
     sp, sps, sch = [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]
     for i, s in enumerate(srcs):
         if s.dtype != dt or s.shape[-1] != pw.src_ch[i] or s.numel() // s.shape[-1] != M:
