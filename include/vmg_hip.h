@@ -175,6 +175,16 @@ int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, 
 int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,
                       float* dw, float* db, int64_t M, int C, void* stream);
 
+/* ---- UpdownkeepSampling (reference: models/layers.py:777-798): the space<->depth rearrangement fused into the LayerNorm that follows it.
+ * The LayerNorm rows are GATHERED from the feature map (forward) and their gradient is scattered back (backward); no rearranged
+ * copy exists.  mode 1 = "down" ('n d c (h neih) (w neiw) -> n d h w (neiw neih c)': x is (N, 2H, 2W, cseg), rows (N*H*W, 4*cseg));
+ * mode 2 = "up" ('n d (neiw neih c) h w -> n d (h neih) (w neiw) c': x is (N, H/2, W/2, 4*cseg), rows (N*H*W, cseg)).  y, dy: contiguous rows;
+ * the Linear of the module is vmg_conv_fwd (KS = 1) on y.  w, b, mean, rstd, dw, db as in vmg_layernorm_fwd / _bwd. */
+int vmg_space_depth_ln_fwd(int dtype, int mode, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int H,
+                           int W, int cseg, float eps, void* stream);
+int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,
+                           float* dw, float* db, int N, int H, int W, int cseg, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * TAB token-mixer tail (models/function.py:542-558 channel attention, :791-802 branch re-weighting + tanh gate).
  * Tensors are (G, R, C) channels-last views (G groups of R rows); per-(group, channel) quantities are fp32.

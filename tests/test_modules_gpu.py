@@ -81,3 +81,37 @@ def test_spynet_matches_reference_fixture():
         scale = max(1.0, float(want.abs().max()))
         assert float((got - want).abs().max()) <= 2e-3 * scale
         assert float(np.abs(C.subsample(got) - ref_outs[0]["sub"]).max()) <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["updown_down", "updown_up"])
+def test_updown_backward_matches_oracle_autograd(name, dtype):
+    """UpdownkeepSampling backward (the fused space<->depth + LayerNorm scatters its input gradient): d/dx and every parameter
+    gradient vs torch autograd through the oracle."""
+    from oracle import cases as C, recipe as R, vmg_oracle as O
+    case = C.CASES[name]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"]
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()
+    mode = "down" if name.endswith("down") else "up"
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.updown(osd, "", xo, mode)
+    go = R.seeded(tuple(want.shape), 95)
+    if dtype == torch.bfloat16:
+        go = go.to(dtype).float()
+    wg = torch.autograd.grad(want, [xo] + [osd[k] for k in sorted(osd)], go)
+    m = _build(name).cuda()
+    m.load_state_dict(sd)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    got = m(xd)
+    got.backward(go.cuda().to(dtype).reshape(got.shape))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert float((got.float().cpu().reshape(want.shape) - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= tol * max(1.0, float(wg[0].abs().max()))
+    params = dict(m.named_parameters())
+    for k, gw in zip(sorted(osd), wg[1:]):
+        err = float((params[k].grad.cpu() - gw).abs().max())
+        assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"

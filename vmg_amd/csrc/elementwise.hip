@@ -82,23 +82,47 @@ struct alignas(sizeof(T) * V) VecN {
   T v[V];
 };
 
+// Row map of the input side (UpdownkeepSampling, models/layers.py:785-793): the LayerNorm row is GATHERED from the feature map, so
+// the space<->depth rearrangement costs no pass of its own.  H, W: grid of the LayerNorm rows; Cseg: channels per segment.
+//   mode 0: rows are contiguous (M, C).
+//   mode 1 ("down", 'n d c (h neih) (w neiw) -> n d h w (neiw neih c)'): row (n, h, w) has 4 segments of Cseg channels; segment
+//           neiw*2 + neih comes from pixel (2h + neih, 2w + neiw) of the (2H, 2W, Cseg) input.
+//   mode 2 ("up", 'n d (neiw neih c) h w -> n d (h neih) (w neiw) c'): row (n, y, x) of the (H, W) output grid is the Cseg-channel
+//           slice (x%2)*2 + (y%2) of pixel (y/2, x/2) of the (H/2, W/2, 4*Cseg) input.
+struct LnMap {
+  int mode, H, W, Cseg;
+};
+__device__ __forceinline__ long long ln_src_elem(const LnMap& m, long long row, int c, int C) {
+  if (m.mode == 0) return row * C + c;
+  const long long hw = (long long)m.H * m.W;
+  const long long n = row / hw;
+  const int rem = (int)(row - n * hw);
+  const int y = rem / m.W, x = rem - y * m.W;
+  if (m.mode == 1) {
+    const int sg = c / m.Cseg, cc = c - sg * m.Cseg;
+    const int neiw = sg >> 1, neih = sg & 1;
+    return (((n * 2 * m.H + 2 * y + neih) * (2 * m.W)) + 2 * x + neiw) * m.Cseg + cc;
+  }
+  const int sg = (x & 1) * 2 + (y & 1);
+  return ((n * (m.H >> 1) + (y >> 1)) * (m.W >> 1) + (x >> 1)) * (4LL * m.Cseg) + sg * m.Cseg + c;
+}
+
 template <typename T, int V, int G>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, long long M,
-                                                            int C, float eps) {
+                                                            int C, float eps, const LnMap map) {
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
   for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += (long long)gridDim.x * groups_per_block) {
-    const T* xr = x + row * C;
     VecN<T, V> buf[LN_MAXV];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
       const int vi = gl + k * G;
       if (vi < nvec) {
-        buf[k] = reinterpret_cast<const VecN<T, V>*>(xr)[vi];
+        buf[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, row, vi * V, C));
 #pragma unroll
         for (int e = 0; e < V; ++e) s += to_f32(buf[k].v[e]);
       }
@@ -142,7 +166,8 @@ template <typename T, int V, int G>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
-                                                            float* __restrict__ dw, float* __restrict__ db, long long M, int C) {
+                                                            float* __restrict__ dw, float* __restrict__ db, long long M, int C,
+                                                            const LnMap map) {
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
@@ -159,7 +184,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int k = 0; k < LN_MAXV; ++k) {
       const int vi = gl + k * G;
       if (vi < nvec) {
-        bx[k] = reinterpret_cast<const VecN<T, V>*>(x + row * C)[vi];
+        bx[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, row, vi * V, C));
         bg[k] = reinterpret_cast<const VecN<T, V>*>(dy + row * C)[vi];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -188,7 +213,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           const float g = to_f32(bg[k].v[e]) * w[c];
           o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
         }
-        reinterpret_cast<VecN<T, V>*>(dx + row * C)[vi] = o;
+        *reinterpret_cast<VecN<T, V>*>(dx + ln_src_elem(map, row, vi * V, C)) = o;
       }
     }
   }
@@ -253,13 +278,13 @@ extern "C" int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, in
 
 template <typename T, int V>
 static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, long long M, int C, float eps,
-                    hipStream_t st) {
+                    hipStream_t st, const LnMap map) {
   const int nvec = C / V;
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
   const int blocks = (int)(cdiv64(M, rows_per_block) > 8192 ? 8192 : cdiv64(M, rows_per_block));
-#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps)
+#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps, map)
   if (G == 16) LN_LAUNCH(16);
   else if (G == 32) LN_LAUNCH(32);
   else LN_LAUNCH(64);
@@ -270,14 +295,14 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
 
 template <typename T, int V>
 static int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
-                    long long M, int C, hipStream_t st) {
+                    long long M, int C, hipStream_t st, const LnMap map) {
   const int nvec = C / V;
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
   const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 1024 ? 1024 : cdiv64(M, rows_per_block * 8));
   const int lds = 2 * C * 4;
-#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C)
+#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map)
   if (G == 16) LN_LAUNCH(16);
   else if (G == 32) LN_LAUNCH(32);
   else LN_LAUNCH(64);
@@ -292,45 +317,83 @@ static int ln_vec(int dtype, int C) {
   return C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);
 }
 
-extern "C" int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
-                                 int64_t M, int C, float eps, void* stream) {
+static int ln_fwd_impl(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t M, int C, float eps,
+                       void* stream, const LnMap map, int vmax) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_fwd: bad dtype");
   VMG_CHECK(x && w && b && y && M > 0 && C > 0, "layernorm_fwd: bad arguments");
   VMG_CHECK(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "layernorm_fwd: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int v = ln_vec(dtype, C);
+  int v = ln_vec(dtype, C);
+  while (v > vmax) v >>= 1;
   if (dtype == VMG_BF16) {
     switch (v) {
-      case 8: return ln_fwd_t<bf16, 8>(x, w, b, y, mean, rstd, M, C, eps, st);
-      case 4: return ln_fwd_t<bf16, 4>(x, w, b, y, mean, rstd, M, C, eps, st);
-      case 2: return ln_fwd_t<bf16, 2>(x, w, b, y, mean, rstd, M, C, eps, st);
-      default: return ln_fwd_t<bf16, 1>(x, w, b, y, mean, rstd, M, C, eps, st);
+      case 8: return ln_fwd_t<bf16, 8>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+      case 4: return ln_fwd_t<bf16, 4>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+      case 2: return ln_fwd_t<bf16, 2>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+      default: return ln_fwd_t<bf16, 1>(x, w, b, y, mean, rstd, M, C, eps, st, map);
     }
   }
   switch (v) {
-    case 4: return ln_fwd_t<float, 4>(x, w, b, y, mean, rstd, M, C, eps, st);
-    case 2: return ln_fwd_t<float, 2>(x, w, b, y, mean, rstd, M, C, eps, st);
-    default: return ln_fwd_t<float, 1>(x, w, b, y, mean, rstd, M, C, eps, st);
+    case 4: return ln_fwd_t<float, 4>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+    case 2: return ln_fwd_t<float, 2>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+    default: return ln_fwd_t<float, 1>(x, w, b, y, mean, rstd, M, C, eps, st, map);
+  }
+}
+
+extern "C" int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 int64_t M, int C, float eps, void* stream) {
+  return ln_fwd_impl(dtype, x, w, b, y, mean, rstd, M, C, eps, stream, LnMap{0, 0, 0, 0}, 8);
+}
+
+// widest vector that divides the segment length of a space<->depth map (a vector must not straddle two segments)
+static int ln_map_vmax(int dtype, int cseg) { return ln_vec(dtype, cseg); }
+static int ln_map_check(int mode, int N, int H, int W, int cseg, int64_t* M, int* C) {
+  VMG_CHECK((mode == 1 || mode == 2) && N > 0 && H > 0 && W > 0 && cseg > 0, "space_depth_ln: mode 1 (down) or 2 (up), positive sizes");
+  VMG_CHECK(mode == 1 || (H % 2 == 0 && W % 2 == 0), "space_depth_ln (up): the output grid must be even");
+  *M = (int64_t)N * H * W;
+  *C = mode == 1 ? 4 * cseg : cseg;
+  return 0;
+}
+
+extern "C" int vmg_space_depth_ln_fwd(int dtype, int mode, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                      int N, int H, int W, int cseg, float eps, void* stream) {
+  int64_t M;
+  int C;
+  if (ln_map_check(mode, N, H, W, cseg, &M, &C)) return -1;
+  return ln_fwd_impl(dtype, x, w, b, y, mean, rstd, M, C, eps, stream, LnMap{mode, H, W, cseg}, ln_map_vmax(dtype, cseg));
+}
+
+static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw,
+                       float* db, int64_t M, int C, void* stream, const LnMap map, int vmax) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_bwd: bad dtype");
+  VMG_CHECK(dy && x && mean && rstd && w && dx && dw && db && M > 0 && C > 0, "layernorm_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int v = ln_vec(dtype, C);
+  while (v > vmax) v >>= 1;
+  if (dtype == VMG_BF16) {
+    switch (v) {
+      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+    }
+  }
+  switch (v) {
+    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
   }
 }
 
 extern "C" int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,
                                  void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
-  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_bwd: bad dtype");
-  VMG_CHECK(dy && x && mean && rstd && w && dx && dw && db && M > 0 && C > 0, "layernorm_bwd: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  const int v = ln_vec(dtype, C);
-  if (dtype == VMG_BF16) {
-    switch (v) {
-      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-    }
-  }
-  switch (v) {
-    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st);
-  }
+  return ln_bwd_impl(dtype, dy, x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{0, 0, 0, 0}, 8);
+}
+
+extern "C" int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,
+                                      void* dx, float* dw, float* db, int N, int H, int W, int cseg, void* stream) {
+  int64_t M;
+  int C;
+  if (ln_map_check(mode, N, H, W, cseg, &M, &C)) return -1;
+  return ln_bwd_impl(dtype, dy, x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{mode, H, W, cseg}, ln_map_vmax(dtype, cseg));
 }

@@ -433,6 +433,32 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _SpaceDepthLayerNorm(torch.autograd.Function):
+    """UpdownkeepSampling's space<->depth rearrangement fused into its LayerNorm (models/layers.py:785-793): rows are gathered from
+    the feature map in the forward and their gradient is scattered back in the backward -- no rearranged copy either way."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, mode):
+        x = x.contiguous()
+        y, mean, rstd = K.space_depth_ln_forward(x, mode, w, b, eps)
+        ctx.mode = mode
+        ctx.save_for_backward(x, mean, rstd, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w = ctx.saved_tensors
+        dx, dw, db = K.space_depth_ln_backward(dy, x, ctx.mode, mean, rstd, w)
+        return dx, dw, db, None, None
+
+
+def space_depth_layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, mode: str) -> torch.Tensor:
+    """x (B,T,H,W,C) -> LayerNorm rows of the 'down' (B,T,H/2,W/2,4C) or 'up' (B,T,2H,2W,C/4) rearrangement, order (neiw neih c)."""
+    B, T, H, W, C = x.shape
+    y = _SpaceDepthLayerNorm.apply(x.reshape(B * T, H, W, C), w, b, eps, mode)
+    return y.reshape(B, T, *y.shape[1:])
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """nn.LayerNorm over the last (channel) dimension."""
     return _LayerNorm.apply(x, w, b, eps)
@@ -678,19 +704,6 @@ class _LTAM(torch.autograd.Function):
 def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):
     """LTAM_multi_head.forward_wins without the output projection (models/trajectory.py:683-774)."""
     return _LTAM.apply(q, loc, rpe, decay_v, (heads, wh, ww, float(scale)), *keys, *vals)
-
-
-def space_to_depth(x: torch.Tensor) -> torch.Tensor:
-    """'n d c (h neih) (w neiw) -> n d h w (neiw neih c)' on channels-last features (models/layers.py:785)."""
-    B, T, H, W, C = x.shape
-    return x.reshape(B, T, H // 2, 2, W // 2, 2, C).permute(0, 1, 2, 4, 5, 3, 6).reshape(B, T, H // 2, W // 2, 4 * C).contiguous()
-
-
-def depth_to_space(x: torch.Tensor) -> torch.Tensor:
-    """'n d (neiw neih c) h w -> n d (h neih) (w neiw) c' (models/layers.py:790)."""
-    B, T, H, W, C = x.shape
-    c4 = C // 4
-    return x.reshape(B, T, H, W, 2, 2, c4).permute(0, 1, 2, 5, 3, 4, 6).reshape(B, T, 2 * H, 2 * W, c4).contiguous()
 
 
 # ---- 3-D shifted windows (models/swin_3d.py) ----------------------------------------------------------

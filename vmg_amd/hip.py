@@ -54,6 +54,9 @@ SIGNATURES = {
     "vmg_pixel_shuffle": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_layernorm_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "vmg_layernorm_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "vmg_space_depth_ln_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "vmg_space_depth_ln_bwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
     "vmg_conv_wgrad_batched": (c_int, [c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int64, c_int,
                                        c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
     "vmg_warp_bilinear_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

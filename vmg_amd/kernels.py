@@ -306,6 +306,47 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
     return dx, dw, db
 
 
+def space_depth_ln_forward(x: torch.Tensor, mode: str, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """UpdownkeepSampling's rearrangement + LayerNorm in one pass.  x: contiguous (N, Hin, Win, Cin); 'down' -> rows (N, Hin/2, Win/2, 4*Cin),
+    'up' -> rows (N, 2*Hin, 2*Win, Cin/4).  Returns (y, mean, rstd)."""
+    hip.require_cuda(x, w, b)
+    N, Hi, Wi, Ci = x.shape
+    if not x.is_contiguous() or w.dtype != torch.float32 or b.dtype != torch.float32:
+        raise HipError("space_depth_ln: contiguous x, fp32 w / b expected")
+    if mode == "down":
+        if Hi % 2 or Wi % 2:
+            raise HipError("space_depth_ln (down): even input size expected")
+        H, W, cseg, C, m = Hi // 2, Wi // 2, Ci, 4 * Ci, 1
+    else:
+        if Ci % 4:
+            raise HipError("space_depth_ln (up): channels must be a multiple of 4")
+        H, W, cseg, C, m = 2 * Hi, 2 * Wi, Ci // 4, Ci // 4, 2
+    if w.numel() != C or b.numel() != C:
+        raise HipError("space_depth_ln: w / b must have the LayerNorm width")
+    y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    mean = torch.empty(N * H * W, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N * H * W, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().vmg_space_depth_ln_fwd(hip.dtype_code(x.dtype), m, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), N, H, W, cseg, eps, hip.stream_ptr()), "vmg_space_depth_ln_fwd")
+    return y, mean, rstd
+
+
+def space_depth_ln_backward(dy: torch.Tensor, x: torch.Tensor, mode: str, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor):
+    hip.require_cuda(dy, x, mean, rstd, w)
+    N, Hi, Wi, Ci = x.shape
+    if mode == "down":
+        H, W, cseg, C, m = Hi // 2, Wi // 2, Ci, 4 * Ci, 1
+    else:
+        H, W, cseg, C, m = 2 * Hi, 2 * Wi, Ci // 4, Ci // 4, 2
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().vmg_space_depth_ln_bwd(hip.dtype_code(x.dtype), m, dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(),
+                                               dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, cseg, hip.stream_ptr()), "vmg_space_depth_ln_bwd")
+    return dx, dw, db
+
+
 def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], dW: torch.Tensor, db: Optional[torch.Tensor], ks: int,
                        N: int, H: int, W: int, scale: float = 1.0, o0: int = 0, i0: int = 0):
     """dW += scale * sum_p wgrad(xs[p], dys[p]) in as few launches as possible (16 pairs per launch)."""

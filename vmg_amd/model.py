@@ -548,8 +548,8 @@ class UpdownkeepSampling(nn.Module):
         self.linear = nn.Linear(cn, dim_out)
 
     def forward(self, x):
-        y = FH.space_to_depth(x) if self.mode == "down" else FH.depth_to_space(x)
-        return lin(self.linear, lnorm(self.norm, y))
+        # rearrangement + LayerNorm are one kernel (the rows are gathered from x); the Linear consumes the normalized rows
+        return lin(self.linear, FH.space_depth_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, self.mode))
 
 
 class InputProj(nn.Module):
