@@ -244,6 +244,15 @@ int vmg_prof_select_pixels(vmg_ctx* ctx, int64_t pixels);
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);
 
+/* ---- SPyNet pyramid pieces (reference: models/vmg.py:39-123), channels-last -----------------------------------------------
+ * vmg_avgpool2_nhwc: F.avg_pool2d(x, 2, 2) of (n, h, w, c) -> (n, h/2, w/2, c)  (:66-70).
+ * vmg_upsample2x_ac_fwd: y (n, 2h, 2w, c) = scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), fp32 (the
+ * flow between pyramid levels, scale = 2, :97-102); _bwd: dx = scale * U^T dy (dx is overwritten).
+ * The 7x7 convolutions of SPyNetBasicModule (:126-173) are vmg_conv_fwd / vmg_conv_wgrad with ks = 7, the warps vmg_warp_bilinear_*. */
+int vmg_avgpool2_nhwc(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
+int vmg_upsample2x_ac_fwd(const float* x, float* y, int n, int h, int w, int c, float scale, void* stream);
+int vmg_upsample2x_ac_bwd(const float* dy, float* dx, int n, int h, int w, int c, float scale, void* stream);
+
 /* ---- sliding-window inference accumulators (reference: tools/Tester.py:107-177, :249-250) --------------------------
  * vmg_tile_accumulate: for a tile `patch` (planes, ph, pw; dtype 0 = f32, 1 = bf16) placed at (oh, ow) of the fp32
  * canvases E and Wt (planes, EH, EW):  E += patch * m,  Wt += m, where m drops the first `top` / last `bottom` rows and

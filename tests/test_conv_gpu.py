@@ -436,3 +436,36 @@ def test_conv_ws_repeatable_and_matches_ksplit():
         else:
             assert torch.equal(got, first), f"launch {i} differs from launch 0"
     assert float((first.float() - ref.float()).abs().max()) <= 2e-2 * max(1.0, float(ref.float().abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------- 7x7 (SPyNet)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 20, 33, 8, 32), (2, 16, 16, 32, 64), (2, 9, 11, 64, 32), (4, 2, 2, 32, 16), (2, 17, 40, 16, 2), (2, 1, 1, 8, 32)])
+def test_conv7x7_fwd_dgrad_wgrad(dtype, shape):
+    """SPyNetBasicModule's convolutions (models/vmg.py:126-173): forward with ReLU, data gradient (flipped pack) and weight / bias
+    gradient of the 7x7 instantiations, incl. 1x1- and 2x2-pixel pyramid levels and the 2-channel flow output."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co = shape
+    x = R.seeded((N, H, W, Ci), 61)
+    w = R.seeded((Co, Ci, 7, 7), 62, (Ci * 49) ** -0.5)
+    b = R.seeded((Co,), 63, 0.1)
+    dy = R.seeded((N, H, W, Co), 64)
+    xq = _q(x, dtype).requires_grad_(True)
+    wq = _q(w, dtype).requires_grad_(True)
+    bq = b.clone().requires_grad_(True)
+    pre = O.conv_nhwc(xq, wq, bq, 3)
+    gx, gw, gb = torch.autograd.grad(pre, (xq, wq, bq), _q(dy, dtype))
+    pw = K.pack_conv_weight(w.cuda(), dtype)
+    got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_RELU)
+    _cmp(got, F.relu(pre.detach()), dtype, f"conv7x7 {shape}")
+    Cop = (Co + 7) // 8 * 8  # the data-gradient's K side (= Co) must be a multiple of 8: zero-padded output channels
+    wp = torch.cat([w, w.new_zeros(Cop - Co, Ci, 7, 7)], 0) if Cop != Co else w
+    dyp = torch.cat([dy, dy.new_zeros(N, H, W, Cop - Co)], -1) if Cop != Co else dy
+    pwd = K.pack_conv_weight(wp.cuda().contiguous(), dtype, transpose_flip=True)
+    gotx, _ = K.conv_forward([dyp.cuda().to(dtype).contiguous()], pwd, None, N, H, W)
+    _cmp(gotx, gx, dtype, f"conv7x7 dgrad {shape}")
+    dW, db = torch.zeros(Co, Ci, 7, 7, device="cuda"), torch.zeros(Co, device="cuda")
+    K.conv_wgrad_batched([x.cuda().to(dtype)], [dy.cuda().to(dtype)], dW, db, 7, N, H, W)
+    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    assert float((dW.cpu() - gw).abs().max()) <= tol * max(1.0, float(gw.abs().max()))
+    assert float((db.cpu() - gb).abs().max()) <= tol * max(1.0, float(gb.abs().max()))

@@ -39,13 +39,13 @@ constexpr int MAX_ISRC = 32;  // internal sources after channel-block splitting
 constexpr int CBMAX = 160;    // max channels per internal source block
 
 // ---- stage geometry shared by the packer, the host launcher and the kernel
-__host__ __device__ constexpr int kstg(int ks) { return ks == 3 ? 3 : 2; }  // k-steps per stage
+__host__ __device__ constexpr int kstg(int ks) { return ks > 1 ? ks : 2; }  // k-steps per stage (a row of taps; 1x1: two channel blocks)
 __host__ __device__ constexpr int stage_bytes(int ks, int ntb, int cb) { return kstg(ks) * 4 * ntb * 16 * cb; }
 __host__ __device__ constexpr int stage_stride(int ks, int ntb, int cb) { return (stage_bytes(ks, ntb, cb) + 4095) / 4096 * 4096; }
-// stages of one source block of `ch` channels: 32-channel blocks x 3 tap rows (3x3) or pairs of blocks (1x1)
+// stages of one source block of `ch` channels: 32-channel blocks x KS tap rows (KS x KS) or pairs of blocks (1x1)
 __host__ __device__ inline int stages_of(int ks, int ch) {
   const int nb = (ch / 8 + 3) / 4;
-  return ks == 3 ? 3 * nb : (nb + 1) / 2;
+  return ks > 1 ? ks * nb : (nb + 1) / 2;
 }
 
 struct ConvK {
@@ -143,8 +143,8 @@ template <typename T, int KS, int MT>
 __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, int n, int ty, int tx, long long m0, int tid) {
   constexpr int ES = ElemTraits<T>::ES;
   constexpr int TH = 4 * MT;
-  constexpr int TWH = (KS == 3) ? 18 : 16;
-  constexpr int THH = (KS == 3) ? TH + 2 : TH;
+  constexpr int TWH = 16 + KS - 1;
+  constexpr int THH = TH + KS - 1;
   const int lane = tid & 63, wave = tid >> 6;
   const int ch = a.src_ch[s], pixb = a.src_pixb[s];
       const char* sp = a.src[s];
@@ -163,15 +163,15 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
         const int dr = 256 / row_vecs, drem = 256 - dr * row_vecs;
         // tile origin as a wave-uniform 64-bit pointer (may lie before the tensor for border tiles: only in-image lanes use
         // it); per lane a 32-bit offset -- (r*W + p)*ps_b + 16v stays far below 2^31 for r <= THH, W <= 8192
-        const int y0 = (KS == 3) ? ty * TH - 1 : 0, x0 = (KS == 3) ? tx * 16 - 1 : 0;
-        const char* origin = (KS == 3) ? sp + (((long long)n * a.H + y0) * a.W + x0) * ps_b : sp + m0 * ps_b;
-        const int ps32 = (int)ps_b, rowstep = ((KS == 3) ? a.W : 16) * ps32;
+        const int y0 = (KS > 1) ? ty * TH - KS / 2 : 0, x0 = (KS > 1) ? tx * 16 - KS / 2 : 0;
+        const char* origin = (KS > 1) ? sp + (((long long)n * a.H + y0) * a.W + x0) * ps_b : sp + m0 * ps_b;
+        const int ps32 = (int)ps_b, rowstep = ((KS > 1) ? a.W : 16) * ps32;
         const long long mleft = a.M - m0;  // KS == 1: pixels from the tile start to the end of the matrix
         for (int i0 = wave * 64; i0 < total; i0 += 256) {
           const int p = (int)(((float)rem + 0.5f) * inv_vpp);  // exact for these ranges (rem < 2^16, vpp <= 40)
           const int v = rem - p * vpp;
           bool ok = r < THH;
-          if (KS == 3) ok = ok && (unsigned)(y0 + r) < (unsigned)a.H && (unsigned)(x0 + p) < (unsigned)a.W;
+          if (KS > 1) ok = ok && (unsigned)(y0 + r) < (unsigned)a.H && (unsigned)(x0 + p) < (unsigned)a.W;
           else ok = ok && (long long)(r * 16 + p) < mleft;
           const int off = r * rowstep + p * ps32 + v * 16;
           const char* gp = ok ? origin + off : reinterpret_cast<const char*>(&g_conv_zero16);
@@ -200,9 +200,9 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
             const int v = ic - p * vpp;
             dsto[b] = i < total ? p * pixb + v * 16 : -1;
             long long goff;
-            if (KS == 3) {
+            if (KS > 1) {
               const int r = p / TWH, c = p - r * TWH;
-              const int y = ty * TH + r - 1, x = tx * 16 + c - 1;
+              const int y = ty * TH + r - KS / 2, x = tx * 16 + c - KS / 2;
               inb[b] = y >= 0 && y < a.H && x >= 0 && x < a.W;
               goff = (((long long)n * a.H + y) * a.W + x) * ps_b + v * 16;
             } else {
@@ -238,7 +238,7 @@ struct Raw4<float> {
 // pixel of lane px in row `row` of the workgroup's tile
 template <int KS>
 __device__ __forceinline__ bool conv_row_pixel(const ConvK& a, int row, int TH, int n, int ty, int tx, long long m0, int px, long long& pix) {
-  if (KS == 3) {
+  if (KS > 1) {
     const int y = ty * TH + row, x = tx * 16 + px;
     pix = ((long long)n * a.H + y) * a.W + x;
     return (y < a.H) && (x < a.W);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& a, const f32x4 (&
     long long pix;
     bool valid;
     int y = 0, x = 0;
-    if (KS == 3) {
+    if (KS > 1) {
       y = ty * TH + row;
       x = tx * 16 + px;
       valid = (y < a.H) && (x < a.W);
@@ -373,8 +373,8 @@ template <typename T, int KS, int MT, int NTB, bool DEEP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
   constexpr int TH = 4 * MT;
-  constexpr int TWH = (KS == 3) ? 18 : 16;
-  constexpr int THH = (KS == 3) ? TH + 2 : TH;
+  constexpr int TWH = 16 + KS - 1;
+  constexpr int THH = TH + KS - 1;
   constexpr int COB = NTB * 16;
   constexpr int KSTG = kstg(KS), RING = DEEP ? 3 : 2;
   constexpr int SS = stage_stride(KS, NTB, CB);  // stage image size in LDS and in the packed weights
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
   const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
   int n = 0, ty = 0, tx = 0;
   long long m0 = 0;
-  if (KS == 3) {
+  if (KS > 1) {
     int bid = xcd_remap(blockIdx.x, gridDim.x, a.dbg);
     tx = bid % a.tiles_x;
     int r = bid / a.tiles_x;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = wave * MT + mt;
-      pixp[mt] = halo + ((KS == 3) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb);
+      pixp[mt] = halo + ((KS > 1) ? (row * TWH + px) * pixb : (row * 16 + px) * pixb);
     }
 
     const int nst_s = (VMG_DBG(a, 32) ? 0 : a.src_nst[s]);
@@ -451,11 +451,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 
       // activation-operand offsets of the KSTG k-steps (zero-weight padding chunks read the last real chunk)
       int boff[KSTG];
-      if (KS == 3) {
+      if (KS > 1) {
         const int base = ky * (TWH * pixb) + min(4 * cbk + g, CH - 1) * CB;
 #pragma unroll
         for (int j = 0; j < KSTG; ++j) boff[j] = base + j * pixb;
-        if (++ky == 3) { ky = 0; ++cbk; }
+        if (++ky == KS) { ky = 0; ++cbk; }
       } else {
 #pragma unroll
         for (int j = 0; j < KSTG; ++j) boff[j] = min(4 * (2 * sl + j) + g, CH - 1) * CB;
@@ -600,7 +600,7 @@ template <typename T, int KS, int NTB>
 __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(const ConvK a) {
   constexpr int ES = ElemTraits<T>::ES, CB = ElemTraits<T>::CHUNKB;
   constexpr int TH = 4;
-  constexpr int TWH = (KS == 3) ? 18 : 16;
+  constexpr int TWH = 16 + KS - 1;
   constexpr int COB = NTB * 16;
   constexpr int SS = stage_stride(KS, NTB, CB);
   constexpr int KSB = 4 * COB * CB;  // bytes of one k-step in a stage image
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
   const int nt_real = min(NTB, (a.Cout - cb * COB + 15) >> 4);
   int n = 0, ty = 0, tx = 0;
   long long m0 = 0;
-  if (KS == 3) {
+  if (KS > 1) {
     int bid = xcd_remap(blockIdx.x, gridDim.x, a.dbg);
     tx = bid % a.tiles_x;
     int r = bid / a.tiles_x;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
     __syncthreads();
     conv_stamp(a, wave, 4);
 
-    const int nks = VMG_DBG(a, 32) ? 0 : (KS == 3 ? 9 * nb : nb);  // k-steps of this source
+    const int nks = VMG_DBG(a, 32) ? 0 : (KS > 1 ? 9 * nb : nb);  // k-steps of this source
     const int per = ((nks + 3) / 4 + 2) / 3 * 3;                 // per wave, padded to the unroll
     const int k0 = wave * per;
     const int rowb = TWH * pixb;  // LDS bytes per tile row (KS == 1: TWH = 16 pixels)
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
       Cur c;
       c.k = k;
       const int kc = min(k, nks - 1);
-      if (KS == 3) {
+      if (KS > 1) {
         c.cbk = kc / 9;
         const int tap = kc - 9 * c.cbk;
         c.ky = tap / 3;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
     auto advance = [&](Cur& c) {
       ++c.k;
       if (c.k < nks) {
-        if (KS == 3) {
+        if (KS > 1) {
           c.woff += KSB;
           if (++c.kx == 3) {
             c.kx = 0;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
     };
     auto load_x = [&](int set) {
       const bool real = cx.k < nks;
-      const int boff = (KS == 3 ? cx.ky * rowb + cx.kx * pixb : 0) + min(4 * cx.cbk + g, CH - 1) * CB;
+      const int boff = (KS > 1 ? cx.ky * rowb + cx.kx * pixb : 0) + min(4 * cx.cbk + g, CH - 1) * CB;
       const char* base = real ? pixp + boff : zslot;
 #pragma unroll
       for (int i = 0; i < 4; ++i) xf[set][i].load(base + (real ? rowoff[i] : 0));
@@ -1318,7 +1318,7 @@ __global__ void conv_pack_kernel(const PackK p) {
       const int sl = stage - p.src_st0[s];
       const int CH = p.src_ch[s] >> 3;
       int tap, q;
-      if (p.ks == 3) { const int cbk = sl / 3, ky = sl - 3 * cbk; tap = ky * 3 + j; q = 4 * cbk + g; }
+      if (p.ks > 1) { const int cbk = sl / p.ks, ky = sl - p.ks * cbk; tap = ky * p.ks + j; q = 4 * cbk + g; }
       else { tap = 0; q = 4 * (2 * sl + j) + g; }
       const int col = cb * p.cob + co;  // output channel within [0, on)
       if (q < CH && col < p.on) {
@@ -1419,7 +1419,7 @@ int launch_conv(const ConvK& k, int ncb, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
+  long long nblk = (KS > 1) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64 * MT);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
   // the dominant kernel class of the path: bf16 3x3, one source of 144 channels, 144 outputs (trajectory chains)
   const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
@@ -1444,6 +1444,18 @@ int dispatch_ntb(const ConvK& k, int ntb, int ncb, hipStream_t st) {
   return -1;
 }
 
+// 7x7 (SPyNet's convs, models/vmg.py:126-173): the pixel-split kernel with 1, 2 or 4 output-channel tiles per workgroup
+template <typename T>
+int dispatch_ks7(const ConvK& k, int ntb, int ncb, hipStream_t st) {
+  switch (ntb) {
+    case 1: return launch_conv<T, 7, 1, 1, false>(k, ncb, st);
+    case 2: return launch_conv<T, 7, 1, 2, false>(k, ncb, st);
+    case 4: return launch_conv<T, 7, 1, 4, false>(k, ncb, st);
+  }
+  vmg_set_error("conv (7x7): cout_tiles must be 1, 2 or 4 (got %d)", ntb);
+  return -1;
+}
+
 template <typename T, int KS, int NTB>
 int launch_ksplit(const ConvK& k, int ncb, int halo_total, hipStream_t st) {
   const int scratch = 12 * NTB * 1024;
@@ -1456,7 +1468,7 @@ int launch_ksplit(const ConvK& k, int ncb, int halo_total, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  long long nblk = (KS == 3) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64);
+  long long nblk = (KS > 1) ? (long long)k.N * k.tiles_y * k.tiles_x : cdiv64(k.M, 64);
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
   ConvK kk = k;
   kk.halo_bytes = lds - 16 - NTB * 16 * 4;  // zero slot and bias sit behind max(halo, scratch)
@@ -1545,7 +1557,7 @@ extern "C" int vmg_conv_debug_stamps(void* buf) {  // diagnostics builds only (t
 extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, const int* src_ch, int cout_tiles) {
   short xoff[MAX_ISRC], xch[MAX_ISRC];
   const int n = expand_sources(nsrc, nullptr, src_ch, xoff, xch, nullptr);
-  if (n < 0 || cout_tiles <= 0 || (ks != 1 && ks != 3)) return -1;
+  if (n < 0 || cout_tiles <= 0 || (ks != 1 && ks != 3 && ks != 7)) return -1;
   int64_t nst = 0;
   for (int s = 0; s < n; ++s) nst += stages_of(ks, xch[s]);
   const int cob = cout_tiles * 16;
@@ -1555,7 +1567,7 @@ extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, cons
 
 extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
                              const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream) {
-  VMG_CHECK(ks == 1 || ks == 3, "conv_pack: ks must be 1 or 3");
+  VMG_CHECK(ks == 1 || ks == 3 || ks == 7, "conv_pack: ks must be 1, 3 or 7");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_pack: bad dtype");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "conv_pack: nsrc must be 1..4");
   VMG_CHECK(!transpose_flip || nsrc == 1, "conv_pack: data-gradient packing takes one K slice");
@@ -1630,7 +1642,7 @@ extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int
 
 extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   VMG_CHECK(d != nullptr, "conv_fwd: null descriptor");
-  VMG_CHECK(d->ks == 1 || d->ks == 3, "conv_fwd: ks must be 1 or 3");
+  VMG_CHECK(d->ks == 1 || d->ks == 3 || d->ks == 7, "conv_fwd: ks must be 1, 3 or 7");
   VMG_CHECK(d->dtype == VMG_F32 || d->dtype == VMG_BF16, "conv_fwd: bad dtype");
   VMG_CHECK(d->nsrc >= 1 && d->nsrc <= 4, "conv_fwd: nsrc must be 1..4");
   VMG_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv_fwd: bad shape");
@@ -1650,9 +1662,10 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   const int ntb = d->cout_tiles;
   VMG_CHECK(ntb > 0, "conv_fwd: cout_tiles must be positive");
   const int ncb = cdiv(d->Cout, ntb * 16);
+  if (d->ks == 7) mt = 1;
   if (mt == 0) mt = 1;  // measured (tools/bench_conv.py): one 16-pixel row per wave keeps 2 workgroups per CU and wins everywhere
   VMG_CHECK(mt == 1 || mt == 2, "conv_fwd: mt must be 1 or 2");
-  const int TH = 4 * mt, TWH = d->ks == 3 ? 18 : 16, THH = d->ks == 3 ? TH + 2 : TH;
+  const int TH = 4 * mt, TWH = 16 + d->ks - 1, THH = TH + d->ks - 1;
   int kt = 0, halo = 0;
   for (int s = 0; s < n; ++s) {
     const int par = parent[s];
@@ -1712,6 +1725,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     // (a hint: anything it does not cover -- padded LDS stride, several sources, unaligned rows -- takes the general kernel below)
     return ntb == 3 ? launch_linear_wres<3>(k, ncb, st) : launch_linear_wres<5>(k, ncb, st);
   }
+  if (d->ks == 7) return d->dtype == VMG_BF16 ? dispatch_ks7<bf16>(k, ntb, ncb, st) : dispatch_ks7<float>(k, ntb, ncb, st);
   if (d->deep == 2) {
     VMG_CHECK(d->dtype == VMG_BF16 && mt == 1, "conv_fwd: the k-split variant is bf16, mt = 1");
     return d->ks == 3 ? dispatch_ksplit<bf16, 3>(k, ntb, ncb, k.halo_bytes, st) : dispatch_ksplit<bf16, 1>(k, ntb, ncb, k.halo_bytes, st);

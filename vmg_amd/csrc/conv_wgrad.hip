@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     const char* dybase = a.dy[pair];
     int n = 0, y = 0, x0 = 0;
     long long m0 = 0;
-    if (KS == 3) {
+    if (KS > 1) {
       const int seg = (int)(u % a.SEG);
       const long long r = u / a.SEG;
       y = (int)(r % a.H);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       const int c = ob + v * C::VPL;
       bool ok = (idx < 32 * C::DY_VPP);
       long long pix;
-      if (KS == 3) { ok = ok && (x0 + p < a.W); pix = ((long long)n * a.H + y) * a.W + x0 + p; }
+      if (KS > 1) { ok = ok && (x0 + p < a.W); pix = ((long long)n * a.H + y) * a.W + x0 + p; }
       else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
       if (ok) {
         const char* src = dybase + (pix * a.dy_ps + c) * ES;
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       const int c = ib + v * C::VPL;
       bool ok = (idx < C::XR * C::XW * C::X_VPP);
       long long pix;
-      if (KS == 3) {
+      if (KS > 1) {
         const int r = p / C::XW, col = p - r * C::XW;
-        const int yy = y + r - 1, xx = x0 + col - 1;
+        const int yy = y + r - KS / 2, xx = x0 + col - KS / 2;
         ok = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
         pix = ((long long)n * a.H + yy) * a.W + xx;
       } else {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, 0, ct * 16, lane);
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
-        const int ky = (KS == 3) ? t / 3 : 0, kx = (KS == 3) ? t % 3 : 0;
+        const int ky = t / KS, kx = t % KS;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
           const bf16x8 bfg = tr_frag(xt + ky * C::XW * C::X_RS, C::X_RS, kx, it * 16, lane);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
         for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const float*>(dyt + (4 * j + g) * C::DY_RS + (ct * 16 + l15) * 4);
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
-          const int ky = (KS == 3) ? t / 3 : 0, kx = (KS == 3) ? t % 3 : 0;
+          const int ky = t / KS, kx = t % KS;
 #pragma unroll
           for (int it = 0; it < IT; ++it) {
             const float bv = *reinterpret_cast<const float*>(xt + (ky * C::XW + 4 * j + g + kx) * C::X_RS + (it * 16 + l15) * 4);
@@ -288,7 +288,7 @@ int launch_wgrad(WgradK k, hipStream_t st) {
 
 static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps,
                       int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale, void* stream) {
-  VMG_CHECK(ks == 1 || ks == 3, "conv_wgrad: ks must be 1 or 3");
+  VMG_CHECK(ks == 1 || ks == 3 || ks == 7, "conv_wgrad: ks must be 1, 3 or 7");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_wgrad: bad dtype");
   VMG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
   VMG_CHECK(npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW, "conv_wgrad: 1..%d (x, dy) pairs", WG_MAX_PAIRS);
@@ -308,9 +308,10 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
   k.dW = dW; k.I_total = I_total; k.o0 = o0; k.i0 = i0; k.db = db; k.scale = scale;
   k.N = N; k.H = H; k.W = W; k.M = (long long)N * H * W;
   k.SEG = cdiv(W, 32);
-  k.Upair = ks == 3 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
+  k.Upair = ks > 1 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
   k.U = k.Upair * npairs;
   hipStream_t st = (hipStream_t)stream;
+  if (ks == 7) return dtype == VMG_BF16 ? launch_wgrad<bf16, 7, 1, 1>(k, st) : launch_wgrad<float, 7, 1, 1>(k, st);  // 49 taps x one 16 x 16 tile per workgroup
   if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
   return ks == 3 ? launch_wgrad<float, 3, 3, 1>(k, st) : launch_wgrad<float, 1, 3, 3>(k, st);
 }

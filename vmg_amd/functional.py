@@ -136,6 +136,7 @@ class _DeferredWgrad:
         self.uses = {}      # (generation, id(param)) -> outstanding forward uses
         self.pending = {}   # id(param) -> [weight, bias, entries]
         self.callbacks = []  # called with each parameter whose .grad has just been completed
+        self.managed = set()  # ids of the parameters (weights and their biases) whose gradient is completed HERE, not by autograd
         self._queued = False
 
     def begin_forward(self):
@@ -146,9 +147,12 @@ class _DeferredWgrad:
             for key in [k for k in self.uses if k[0] < lo]:
                 del self.uses[key]
 
-    def note_use(self, weight) -> int:
+    def note_use(self, weight, bias=None) -> int:
         key = (self.gen, id(weight))
         self.uses[key] = self.uses.get(key, 0) + 1
+        self.managed.add(id(weight))
+        if bias is not None:
+            self.managed.add(id(bias))
         return self.gen
 
     def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0):
@@ -223,6 +227,7 @@ def set_wgrad_mode(mode: str):
         raise HipError(f"wgrad mode {mode!r}: 'autograd' or 'deferred'")
     if mode != DEFERRED.mode:
         DEFERRED.flush_all()
+        DEFERRED.managed.clear()
         DEFERRED.mode = mode
 
 
@@ -262,7 +267,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[0] and \
             (bias is None or isinstance(bias, torch.nn.Parameter))
         if ctx.defer:
-            ctx.gen = DEFERRED.note_use(weight)
+            ctx.gen = DEFERRED.note_use(weight, bias)
             ctx.bias_ref = bias
         # relu / lrelu derivatives come from the sign of the output (taken before the residual is added, so keep
         # the sign information only when there is no residual; with a residual the activation is NONE on this path)
@@ -349,8 +354,8 @@ class _ResidualChain(torch.autograd.Function):
         ctx.wgrad = any(ctx.needs_input_grad[2 + nsrc:])
         ctx.defer = ctx.wgrad and DEFERRED.mode == "deferred"
         if ctx.defer:
-            for p in params[0::2]:
-                ctx.gen = DEFERRED.note_use(p)
+            for p, pb in zip(params[0::2], params[1::2]):
+                ctx.gen = DEFERRED.note_use(p, pb)
         ctx.params = params
         ctx.save_for_backward(*srcs, *saved[:-1])  # the final output is not needed
         return y
@@ -631,6 +636,24 @@ class _TanhGate(torch.autograd.Function):
 
 def tanh_gate(x, y):
     return _TanhGate.apply(x, y)
+
+
+class _Upsample2xAC(torch.autograd.Function):
+    """scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) on channels-last fp32 (SPyNet's flow between
+    pyramid levels, models/vmg.py:97-102)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return K.upsample2x_ac(x.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.upsample2x_ac(dy.contiguous(), ctx.scale, backward=True), None
+
+
+def upsample2x_flow(x: torch.Tensor, scale: float = 2.0) -> torch.Tensor:
+    return _Upsample2xAC.apply(x, float(scale))
 
 
 def identity_grid(n: int, h: int, w: int, device) -> torch.Tensor:

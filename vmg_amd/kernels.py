@@ -19,12 +19,14 @@ def _intarr(v: Sequence[int]):
     return (ctypes.c_int * len(v))(*[int(x) for x in v])
 
 
-def cout_tiles_for(cout: int, dtype: torch.dtype = torch.bfloat16) -> int:
+def cout_tiles_for(cout: int, dtype: torch.dtype = torch.bfloat16, ks: int = 3) -> int:
     """16-channel tiles per workgroup: 9 covers C = 144/288/576 exactly, 7 covers 112/224/448, 8 covers 128/256; otherwise
     the candidate with the least padding.  fp32 (the parity path) has twice the bytes per stage: at most 5 tiles."""
     t = (cout + 15) // 16
     if t <= 1:
         return 1
+    if ks == 7:  # SPyNet's 7x7 convs (2 .. 64 output channels): 1, 2 or 4 tiles
+        return 2 if t == 2 else 4
     if t <= 4:
         return 4
     best, waste = None, None
@@ -69,7 +71,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
             acc += c
     if on is None:
         on = odim - o0
-    tiles = cout_tiles if cout_tiles else cout_tiles_for(on, dtype)
+    tiles = cout_tiles if cout_tiles else cout_tiles_for(on, dtype, ks)
     code = hip.dtype_code(dtype)
     l = hip.lib()
     nbytes = l.vmg_conv_pack_bytes(code, ks, on, len(src_ch), _intarr(src_ch), tiles)
@@ -304,6 +306,34 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
                                           w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
               "vmg_layernorm_bwd")
     return dx, dw, db
+
+
+def avgpool2(x: torch.Tensor) -> torch.Tensor:
+    """F.avg_pool2d(x, 2, 2) on a contiguous channels-last (n, h, w, c) tensor."""
+    hip.require_cuda(x)
+    n, h, w, c = x.shape
+    if not x.is_contiguous() or h < 2 or w < 2:
+        raise HipError("avgpool2: contiguous (n,h,w,c) with h, w >= 2 expected")
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().vmg_avgpool2_nhwc(hip.dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), n, h, w, c, hip.stream_ptr()), "vmg_avgpool2_nhwc")
+    return y
+
+
+def upsample2x_ac(x: torch.Tensor, scale: float, backward: bool = False) -> torch.Tensor:
+    """forward: (n,h,w,c) fp32 -> scale * bilinear x2 (align_corners=True) (n,2h,2w,c); backward: the transpose on (n,2h,2w,c)."""
+    hip.require_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
+        raise HipError("upsample2x_ac: contiguous fp32 (n,h,w,c) expected")
+    n, h, w, c = x.shape
+    if not backward:
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().vmg_upsample2x_ac_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, scale, hip.stream_ptr()), "vmg_upsample2x_ac_fwd")
+        return y
+    if h % 2 or w % 2:
+        raise HipError("upsample2x_ac backward: even gradient size expected")
+    dx = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().vmg_upsample2x_ac_bwd(x.data_ptr(), dx.data_ptr(), n, h // 2, w // 2, c, scale, hip.stream_ptr()), "vmg_upsample2x_ac_bwd")
+    return dx
 
 
 def space_depth_ln_forward(x: torch.Tensor, mode: str, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):

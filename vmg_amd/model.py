@@ -53,17 +53,15 @@ def flow_warp_nhwc(x: torch.Tensor, flow: torch.Tensor, mode: str = "bilinear", 
 
 
 # ---------------------------------------------------------------------------------------------------------
-# SPyNet (models/vmg.py:18-173).  2-4 % of the FLOPs; stays on PyTorch-ROCm ops this round.
+# SPyNet (models/vmg.py:18-173) on the HIP kernels: 7x7 convolutions = the implicit-GEMM kernel (KS = 7) with fused ReLU,
+# pyramid = vmg_avgpool2_nhwc, flow up-sampling = vmg_upsample2x_ac, warps = vmg_warp_bilinear.  Channels-last throughout;
+# the flow itself (up-sampling, warp coordinates, the residual accumulation over levels) stays fp32 in every compute dtype.
 # ---------------------------------------------------------------------------------------------------------
-class _ConvModule(nn.Module):
+class _ConvModule(nn.Module):  # mmcv ConvModule naming: `.conv` holds the parameters (state-dict keys ...conv.weight / ...conv.bias)
     def __init__(self, cin, cout, act):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, 7, 1, 3)
         self.act = act
-
-    def forward(self, x):
-        x = self.conv(x)
-        return F.relu(x) if self.act else x
 
 
 class SPyNetBasicModule(nn.Module):
@@ -72,17 +70,13 @@ class SPyNetBasicModule(nn.Module):
         self.basic_module = nn.Sequential(_ConvModule(8, 32, True), _ConvModule(32, 64, True), _ConvModule(64, 32, True),
                                           _ConvModule(32, 16, True), _ConvModule(16, 2, False))
 
-    def forward(self, x):
-        return self.basic_module(x)
-
-
-def _warp_nchw(x, flow_nhw2, padding):
-    n, c, h, w = x.shape
-    ys, xs = torch.meshgrid(torch.arange(h, device=x.device), torch.arange(w, device=x.device), indexing="ij")
-    g = torch.stack((xs, ys), 2).to(x.dtype) + flow_nhw2
-    gx = 2.0 * g[..., 0] / max(w - 1, 1) - 1.0
-    gy = 2.0 * g[..., 1] / max(h - 1, 1) - 1.0
-    return F.grid_sample(x, torch.stack((gx, gy), 3), mode="bilinear", padding_mode=padding, align_corners=True)
+    def forward(self, srcs: Sequence[torch.Tensor]) -> torch.Tensor:
+        """srcs: channels-last tensors whose channels concatenate to the 8 input channels [ref, warped, flow] -> (n,h,w,2)."""
+        n, h, w = srcs[0].shape[:3]
+        y = list(srcs)
+        for m in self.basic_module:
+            y = [FH.conv2d(y, m.conv.weight, m.conv.bias, n, h, w, ks=7, act=ACT_RELU if m.act else hip.ACT_NONE)]
+        return y[0]
 
 
 class SPyNet(nn.Module):
@@ -102,29 +96,45 @@ class SPyNet(nn.Module):
         self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
         self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
-    def compute_flow(self, ref, supp):
-        n, _, h, w = ref.size()
-        ref = [(ref - self.mean) / self.std]
-        supp = [(supp - self.mean) / self.std]
-        for _ in range(5):
-            ref.append(F.avg_pool2d(ref[-1], 2, 2, count_include_pad=False))
-            supp.append(F.avg_pool2d(supp[-1], 2, 2, count_include_pad=False))
-        ref, supp = ref[::-1], supp[::-1]
-        flow = ref[0].new_zeros(n, 2, h // 32, w // 32)
+    def compute_flow(self, ref: torch.Tensor, supp: torch.Tensor) -> torch.Tensor:
+        """ref, supp: channels-last (n,h,w,8) in the compute dtype, normalised RGB in channels 0..2 and zeros behind (the warp
+        kernel moves 16-byte channel vectors), h and w multiples of 32 -> flow (n,h,w,2) fp32 (models/vmg.py:39-85)."""
+        from . import kernels as K
+        n, h, w, _ = ref.shape
+        dt = ref.dtype
+        refs, supps = [ref], [supp]
+        with torch.no_grad():  # the pyramid of the input frames needs no gradient
+            for _ in range(5):
+                refs.append(K.avgpool2(refs[-1]))
+                supps.append(K.avgpool2(supps[-1]))
+        refs, supps = refs[::-1], supps[::-1]
+        flow = torch.zeros(n, h // 32, w // 32, 2, dtype=torch.float32, device=ref.device)
         for level in range(6):
-            up = flow if level == 0 else F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
-            warped = _warp_nchw(supp[level], up.permute(0, 2, 3, 1), "border")
-            flow = up + self.basic_module[level](torch.cat([ref[level], warped, up], 1))
+            up = flow if level == 0 else FH.upsample2x_flow(flow, 2.0)
+            warped = FH.grid_sample_flow(supps[level], up, "bilinear", "border")
+            res = self.basic_module[level]([refs[level][..., :3], warped[..., :3], up.to(dt)])
+            flow = up + res.float()
         return flow
 
-    def forward(self, ref, supp):
+    def forward(self, ref, supp, compute_dtype=torch.float32):
+        """ref, supp (n,3,h,w) in [0,1] -> flow (n,2,h,w) from supp to ref, fp32 (models/vmg.py:87-123)."""
+        hip.require_cuda(ref, supp)
         h, w = ref.shape[2:4]
         w_up = w if (w % 32) == 0 else 32 * (w // 32 + 1)
         h_up = h if (h % 32) == 0 else 32 * (h // 32 + 1)
-        ref = F.interpolate(ref, size=(h_up, w_up), mode="bilinear", align_corners=False)
-        supp = F.interpolate(supp, size=(h_up, w_up), mode="bilinear", align_corners=False)
-        flow = F.interpolate(self.compute_flow(ref, supp), size=(h, w), mode="bilinear", align_corners=False)
-        return torch.stack((flow[:, 0] * (float(w) / float(w_up)), flow[:, 1] * (float(h) / float(h_up))), 1)
+        resized = (h_up, w_up) != (h, w)
+
+        def prep(img):
+            img = (img.float() - self.mean) / self.std
+            if resized:  # (sizes that are no multiple of 32: a plain bilinear resize, models/vmg.py:104-113)
+                img = F.interpolate(img, size=(h_up, w_up), mode="bilinear", align_corners=False)
+            return F.pad(img.permute(0, 2, 3, 1), (0, 5)).to(compute_dtype).contiguous()  # channels-last, 3 -> 8 channels
+
+        flow = self.compute_flow(prep(ref), prep(supp)).permute(0, 3, 1, 2)
+        if resized:
+            flow = F.interpolate(flow, size=(h, w), mode="bilinear", align_corners=False)
+            flow = torch.stack((flow[:, 0] * (float(w) / float(w_up)), flow[:, 1] * (float(h) / float(h_up))), 1)
+        return flow
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -670,11 +680,11 @@ class VMG(nn.Module):
             a = xi[:, :-1].reshape(-1, C, h, w)
             b = xi[:, 1:].reshape(-1, C, h, w)
             if self.frames_mirror:
-                ff = self.spynet(b, a).view(B, T - 1, 2, h, w)
+                ff = self.spynet(b, a, self.compute_dtype).reshape(B, T - 1, 2, h, w)
                 fb = ff.flip(1)
             else:  # both directions in ONE SPyNet pass (twice the batch, half the launches; per-sample results unchanged)
-                both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0))
-                ff, fb = both[:a.shape[0]].view(B, T - 1, 2, h, w), both[a.shape[0]:].view(B, T - 1, 2, h, w)
+                both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0), self.compute_dtype).contiguous()
+                ff, fb = both[:a.shape[0]].reshape(B, T - 1, 2, h, w), both[a.shape[0]:].reshape(B, T - 1, 2, h, w)
             fwd.append(ff)
             bwd.append(fb)
         return fwd, bwd

@@ -149,7 +149,7 @@ class GradBucketReducer:
         self.op_avg = backend == "nccl"  # RCCL averages in the collective
         self.enabled = True
         self.side = torch.cuda.Stream() if self.params[0].is_cuda else None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_autograd) for p in self.params]
         self._order_log: List[torch.nn.Parameter] = []
         self._relaid = optimizer is None  # nothing to re-lay out without a flat optimizer
         try:  # conv / linear weights are completed by the deferred batched weight-gradient, not by autograd accumulation
@@ -216,6 +216,17 @@ class GradBucketReducer:
                 flat.div_(self.world)
                 work = None
         self.works.append((bi, work))
+
+    def _on_autograd(self, p: torch.nn.Parameter):
+        """autograd's post-accumulate hook.  It also fires when a backward node returned NO gradient for the parameter (the deferred
+        batched weight gradients do): such parameters are complete only when functional.DEFERRED says so (its callback)."""
+        try:
+            from . import functional as FH
+            if id(p) in FH.DEFERRED.managed:
+                return
+        except Exception:  # pragma: no cover
+            pass
+        self._on_grad(p)
 
     def _on_grad(self, p: torch.nn.Parameter):
         if not self.enabled or p not in self.bucket_of or id(p) in self._seen:
