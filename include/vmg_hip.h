@@ -244,6 +244,13 @@ int vmg_prof_select_pixels(vmg_ctx* ctx, int64_t pixels);
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);
 
+/* ---- multi-scale skip (MDSC; reference: models/vmg.py:388-400, 519, 525): adaptive_max_pool2d to (H/f, W/f) as non-overlapping f x f
+ * windows (f must divide H and W; f = 4 in the model).  idx (N, H/f, W/f, C) bytes: position of the winner inside its window.
+ * The 1x1 conv that follows is vmg_conv_fwd (KS = 1); GroupNorm(1, C) + ReLU is two vmg_group_reduce calls (sum, sum of squares) and
+ * vmg_tab_elementwise op 6 (p0 * k0 + p1 * k1 + add with per-(sample, channel) coefficients, ReLU when s > 0.5). */
+int vmg_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int f, void* stream);
+int vmg_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int f, void* stream);
+
 /* ---- SPyNet pyramid pieces (reference: models/vmg.py:39-123), channels-last -----------------------------------------------
  * vmg_avgpool2_nhwc: F.avg_pool2d(x, 2, 2) of (n, h, w, c) -> (n, h/2, w/2, c)  (:66-70).
  * vmg_upsample2x_ac_fwd: y (n, 2h, 2w, c) = scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), fp32 (the

@@ -115,3 +115,38 @@ def test_updown_backward_matches_oracle_autograd(name, dtype):
     for k, gw in zip(sorted(osd), wg[1:]):
         err = float((params[k].grad.cpu() - gw).abs().max())
         assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mdsc_skip_fwd_bwd(dtype):
+    """The multi-scale skip (adaptive max-pool /4, conv1x1, GroupNorm(1), ReLU; models/vmg.py:388-400) on the HIP kernels vs the
+    oracle's autograd: output, input gradient and all four parameter gradients."""
+    import torch.nn as nn
+    from oracle import recipe as R, vmg_oracle as O
+    from vmg_amd.model import VMG
+    B, T, H, W, C, C2 = 2, 2, 16, 24, 32, 64
+    x = R.seeded((B, T, H, W, C), 71)
+    sd = {"0.weight": R.seeded((C2, C, 1, 1), 72, C ** -0.5), "0.bias": R.seeded((C2,), 73, 0.1), "1.weight": 1 + R.seeded((C2,), 74, 0.1),
+          "1.bias": R.seeded((C2,), 75, 0.1)}
+    if dtype == torch.bfloat16:  # the product rounds activations and the conv weight to bf16: give the oracle the same values
+        x = x.to(dtype).float()
+        sd["0.weight"] = sd["0.weight"].to(dtype).float()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.mdsc_skip(osd, "", xo)
+    go = R.seeded(tuple(want.shape), 76)
+    if dtype == torch.bfloat16:
+        go = go.to(dtype).float()
+    wg = torch.autograd.grad(want, [xo] + [osd[k] for k in sorted(osd)], go)
+    seq = nn.Sequential(nn.Conv2d(C, C2, 1, 1, 0), nn.GroupNorm(1, C2), nn.ReLU()).cuda()
+    seq.load_state_dict(sd)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    got = VMG._mdsc(None, seq, xd)
+    got.backward(go.cuda().to(dtype))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= tol * max(1.0, float(wg[0].abs().max()))
+    params = dict(seq.named_parameters())
+    for k, gw in zip(sorted(osd), wg[1:]):
+        err = float((params[k].grad.cpu().reshape(gw.shape) - gw).abs().max())
+        assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"

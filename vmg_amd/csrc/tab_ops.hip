@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5 };
+enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict__ p0, const T* __restrict__ p1, const T* __restrict__ p2,
@@ -122,6 +122,17 @@ __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict
       *reinterpret_cast<V16<T>*>(o0 + off) = r0;
       *reinterpret_cast<V16<T>*>(o1 + off) = r1;
       *reinterpret_cast<V16<T>*>(o2 + off) = r2;
+    } else if (op == OP_AFFINE2) {  // p0*k0 + p1*k1 + add, coef (G, C, 2), p1 optional; ReLU when s > 0.5 (GroupNorm(1)+ReLU and its backward)
+      V16<T> q;
+      if (p1) q = *reinterpret_cast<const V16<T>*>(p1 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float* k = coef + (gc + e) * 2;
+        float t = to_f32(a.v[e]) * k[0] + add[gc + e];
+        if (p1) t += to_f32(q.v[e]) * k[1];
+        r0.v[e] = from_f32<T>(s > 0.5f ? fmaxf(t, 0.f) : t);
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
     } else if (op == OP_GATE_FWD) {  // (x + y) * tanh(y): p0 = x, p1 = y
       const V16<T> y = *reinterpret_cast<const V16<T>*>(p1 + off);
 #pragma unroll
@@ -146,7 +157,72 @@ __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ f x f max pooling
+// The multi-scale skip of VMG (models/vmg.py:388-400): adaptive_max_pool2d to (H/4, W/4) = non-overlapping 4 x 4 windows when the
+// size divides.  Forward keeps the winner's position inside its window (first maximum in row-major order, as ATen does);
+// backward writes every input element once: the window's gradient at the winner, zero elsewhere (no atomics, no memset).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ src, T* __restrict__ dst, unsigned char* __restrict__ idx, int N, int H,
+                                                      int W, int C, int f) {
+  const int Ho = H / f, Wo = W / f;
+  if (!BWD) {
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      long long t = i / C;
+      const int xo = (int)(t % Wo);
+      t /= Wo;
+      const int yo = (int)(t % Ho);
+      const long long n = t / Ho;
+      float best = -INFINITY;
+      int bi = 0;
+      for (int iy = 0; iy < f; ++iy)
+        for (int ix = 0; ix < f; ++ix) {
+          const float v = to_f32(src[((n * H + yo * f + iy) * W + xo * f + ix) * C + c]);
+          if (v > best || (v != v && best == best)) { best = v; bi = iy * f + ix; }
+        }
+      dst[i] = from_f32<T>(best);
+      idx[i] = (unsigned char)bi;
+    }
+  } else {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      long long t = i / C;
+      const int x = (int)(t % W);
+      t /= W;
+      const int y = (int)(t % H);
+      const long long n = t / H;
+      const long long o = ((n * Ho + y / f) * Wo + x / f) * C + c;
+      const int local = (y % f) * f + (x % f);
+      dst[i] = idx[o] == local ? src[o] : from_f32<T>(0.f);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int vmg_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int f, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "maxpool_fwd: bad dtype");
+  VMG_CHECK(x && y && idx && N > 0 && C > 0 && f > 0 && f <= 15 && H % f == 0 && W % f == 0 && H >= f && W >= f, "maxpool_fwd: the window must divide the image");
+  const long long total = (long long)N * (H / f) * (W / f) * C;
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, idx, N, H, W, C, f);
+  else hipLaunchKernelGGL((maxpool_kernel<float, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, N, H, W, C, f);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int f, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "maxpool_bwd: bad dtype");
+  VMG_CHECK(dy && dx && idx && N > 0 && C > 0 && f > 0 && f <= 15 && H % f == 0 && W % f == 0, "maxpool_bwd: the window must divide the image");
+  const long long total = (long long)N * H * W * C;
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)dx, const_cast<unsigned char*>(idx), N, H, W, C, f);
+  else hipLaunchKernelGGL((maxpool_kernel<float, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)dx, const_cast<unsigned char*>(idx), N, H, W, C, f);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode,
                                 float scale, void* stream) {
@@ -180,7 +256,7 @@ extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const v
 extern "C" int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add,
                                    float s, void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "tab_elementwise: bad dtype");
-  VMG_CHECK(op >= 0 && op <= 5 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
+  VMG_CHECK(op >= 0 && op <= 6 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
   const int vn = dtype == VMG_BF16 ? 8 : 4;
   VMG_CHECK(C % vn == 0, "tab_elementwise: C must be a multiple of %d", vn);
   const long long total = rows * (C / vn);

@@ -638,6 +638,67 @@ def tanh_gate(x, y):
     return _TanhGate.apply(x, y)
 
 
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f):
+        y, idx = K.maxpool_forward(x.contiguous(), f)
+        ctx.f = f
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return K.maxpool_backward(dy, idx, ctx.f), None
+
+
+def max_pool(x: torch.Tensor, f: int) -> torch.Tensor:
+    """adaptive_max_pool2d(x, (H/f, W/f)) on channels-last (n,h,w,c) when f divides h and w (models/vmg.py:519, 525)."""
+    return _MaxPool.apply(x, int(f))
+
+
+class _GroupNorm1ReLU(torch.autograd.Function):
+    """relu(GroupNorm(1, C)(x)) on channels-last (n,h,w,c): per-sample statistics over (h,w,c), per-channel affine
+    (models/vmg.py:390-399).  Two grouped reductions + one coefficient-broadcast elementwise pass each way; the (n, c)-sized
+    algebra in between is a handful of tiny fp32 ops."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        n, c = x.shape[0], x.shape[-1]
+        cnt = x.numel() // n
+        s1 = K.group_reduce(x, n).sum(1)
+        s2 = K.group_reduce(x, n, b=x, mode=1).sum(1)
+        mu = s1 / cnt
+        rs = torch.rsqrt((s2 / cnt - mu * mu).clamp_min(0) + eps)
+        coef = torch.stack([rs[:, None] * w[None], torch.zeros(n, c, device=x.device)], -1).contiguous()
+        add = (b[None] - mu[:, None] * rs[:, None] * w[None]).contiguous()
+        y = K.tab_elementwise(K.OP_AFFINE2, x, coef=coef, add=add, s=1.0, G=n)
+        ctx.save_for_backward(x, y, w, mu, rs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w, mu, rs = ctx.saved_tensors
+        n, c = x.shape[0], x.shape[-1]
+        cnt = x.numel() // n
+        g = K.act_backward(dy.contiguous(), y, hip.ACT_RELU, 0.0, 1.0)   # dy * relu'(y)
+        S1 = K.group_reduce(g, n)                                         # (n, c): sum_r g
+        S2 = K.group_reduce(g, n, b=x, mode=1)                            # (n, c): sum_r g * x
+        gxh = rs[:, None] * (S2 - mu[:, None] * S1)                       # sum_r g * xhat
+        dw, db = gxh.sum(0), S1.sum(0)
+        m1 = (S1 * w[None]).sum(1) / cnt                                  # mean(g * w)
+        m2 = (gxh * w[None]).sum(1) / cnt                                 # mean(g * w * xhat)
+        coef = torch.stack([(rs[:, None] * w[None]).expand(n, c), (-rs * rs * m2)[:, None].expand(n, c)], -1).contiguous()
+        add = (rs * (mu * rs * m2 - m1))[:, None].expand(n, c).contiguous()
+        dx = K.tab_elementwise(K.OP_AFFINE2, g, x, coef=coef, add=add, s=0.0, G=n)
+        return dx, dw, db, None
+
+
+def group_norm1_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    return _GroupNorm1ReLU.apply(x, w, b, float(eps))
+
+
 class _Upsample2xAC(torch.autograd.Function):
     """scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) on channels-last fp32 (SPyNet's flow between
     pyramid levels, models/vmg.py:97-102)."""

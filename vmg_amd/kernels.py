@@ -308,6 +308,28 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
     return dx, dw, db
 
 
+def maxpool_forward(x: torch.Tensor, f: int):
+    """Non-overlapping f x f max pooling of a contiguous channels-last (n,h,w,c) tensor -> (y, idx)."""
+    hip.require_cuda(x)
+    n, h, w, c = x.shape
+    if not x.is_contiguous() or h % f or w % f:
+        raise HipError("maxpool: contiguous (n,h,w,c) with h, w multiples of the window expected")
+    y = torch.empty((n, h // f, w // f, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, h // f, w // f, c), dtype=torch.uint8, device=x.device)
+    hip.check(hip.lib().vmg_maxpool_fwd(hip.dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c, f, hip.stream_ptr()), "vmg_maxpool_fwd")
+    return y, idx
+
+
+def maxpool_backward(dy: torch.Tensor, idx: torch.Tensor, f: int) -> torch.Tensor:
+    hip.require_cuda(dy, idx)
+    n, ho, wo, c = dy.shape
+    dy = dy.contiguous()
+    dx = torch.empty((n, ho * f, wo * f, c), dtype=dy.dtype, device=dy.device)
+    hip.check(hip.lib().vmg_maxpool_bwd(hip.dtype_code(dy.dtype), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, ho * f, wo * f, c, f, hip.stream_ptr()),
+              "vmg_maxpool_bwd")
+    return dx
+
+
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     """F.avg_pool2d(x, 2, 2) on a contiguous channels-last (n, h, w, c) tensor."""
     hip.require_cuda(x)
@@ -495,7 +517,7 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
     return dq, dk, dv, drpe
 
 
-OP_CA_FWD, OP_CA_BWD, OP_MIX_FWD, OP_MIX_BWD, OP_GATE_FWD, OP_GATE_BWD = range(6)
+OP_CA_FWD, OP_CA_BWD, OP_MIX_FWD, OP_MIX_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_AFFINE2 = range(7)
 
 
 def group_reduce(a: torch.Tensor, G: int, b: Optional[torch.Tensor] = None, c3: Optional[torch.Tensor] = None, mode: int = 0,

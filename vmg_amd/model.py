@@ -691,10 +691,14 @@ class VMG(nn.Module):
 
     # ---------------------------------------------------------------------------------------------- trunk
     def _mdsc(self, seq, x):
+        """adaptive_max_pool2d /4 -> conv1x1 -> GroupNorm(1) -> ReLU (models/vmg.py:388-400, 519, 525), channels-last on the HIP kernels."""
         B, T, H, W, C = x.shape
-        f = F.adaptive_max_pool2d(x.reshape(B * T, H, W, C).permute(0, 3, 1, 2).float(), (H // 4, W // 4))
-        f = F.relu(F.group_norm(F.conv2d(f, seq[0].weight, seq[0].bias), 1, seq[1].weight, seq[1].bias, seq[1].eps))
-        return f.permute(0, 2, 3, 1).reshape(B, T, H // 4, W // 4, -1).to(x.dtype)
+        if H % 4 or W % 4:
+            raise HipError("the multi-scale skip pools by 4: stage sizes must be multiples of 4 (they are: the input is padded to a multiple of 8)")
+        f = FH.max_pool(x.reshape(B * T, H, W, C), 4)
+        f = FH.conv2d([f], seq[0].weight, seq[0].bias, B * T, H // 4, W // 4, ks=1)
+        f = FH.group_norm1_relu(f, seq[1].weight, seq[1].bias, seq[1].eps)
+        return f.reshape(B, T, H // 4, W // 4, -1)
 
     def forward_features_multi_stages(self, x, ff, fb):
         enc, dec, down, up = self.encoder_layers, self.decoder_layers, self.downsample, self.upsample
