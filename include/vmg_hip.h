@@ -125,6 +125,40 @@ typedef struct vmg_conv_desc {
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * vmg_resblock_chain_fwd / _bwd -- ResidualBlocksWithInputConv (reference: models/trajectory.py:16-52, 165-221), the 1 + 2*nblk
+ * convolutions of one recurrence step, enqueued by ONE call (no host work between the launches):
+ *     y_0 = lrelu_slope0(conv0(cat(src)) + b0);   t_k = relu(conv1_k(y_k) + b1_k);   y_{k+1} = y_k + r * (conv2_k(t_k) + b2_k)
+ * A persistent single-launch form is not used: every layer boundary is an all-neighbour exchange (3x3 halo), and on MI355X a
+ * grid-wide seam inside a launch costs more than the kernel boundary it replaces.
+ * All tensors (N, H, W, C) channels-last, contiguous, dtype bf16 or fp32; packed weights from vmg_conv_pack / vmg_convws_pack with
+ * cout_tiles / deep as for vmg_conv_fwd (conv0 may use its own: cout_tiles0 / deep0).  y[0..nblk] and t[0..nblk-1] are outputs (kept for
+ * the backward).  Backward: g_y[nblk] = gradient of y_nblk on entry;  g_t[k] = r * dgrad2_k(g_y[k+1]) * relu'(t_k);
+ * g_y[k] = g_y[k+1] + dgrad1_k(g_t[k]);  all g_y / g_t are outputs (the weight gradients take them as operands, vmg_conv_wgrad*).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vmg_chain_desc {
+  int dtype, N, H, W, C, nblk, nsrc;
+  const void* src[4];
+  int64_t src_ps[4];
+  int src_ch[4];
+  const void* packed0; /* forward: conv0's pack; backward: unused */
+  const float* bias0;
+  float slope0;
+  int cout_tiles0, deep0;
+  const void* const* packed1; /* nblk packs of conv1 (forward packs in _fwd, data-gradient packs in _bwd) */
+  const float* const* bias1;
+  const void* const* packed2;
+  const float* const* bias2;
+  float r_scaling;
+  int cout_tiles, deep;
+  void* const* y; /* nblk + 1 tensors */
+  void* const* t; /* nblk tensors */
+  void* const* g_y; /* backward only: nblk + 1 tensors, g_y[nblk] given */
+  void* const* g_t; /* backward only: nblk tensors */
+} vmg_chain_desc;
+int vmg_resblock_chain_fwd(const vmg_chain_desc* d, void* stream);
+int vmg_resblock_chain_bwd(const vmg_chain_desc* d, void* stream);
+
 /* diagnostics: when buf is non-null the k-split variant writes 8 wave-level 100-MHz time stamps per wave
  * (uint64[workgroups][4][8]) at its phase boundaries; null switches it off */
 int vmg_conv_debug_stamps(void* buf);

@@ -1742,3 +1742,51 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   if (d->ks == 3) return dispatch_ntb<float, 3, 1, false>(k, ntb, ncb, st);
   return dispatch_ntb<float, 1, 1, false>(k, ntb, ncb, st);
 }
+
+// ------------------------------------------------------------------------------------------------ residual chains
+static void chain_base(const vmg_chain_desc* c, vmg_conv_desc& d) {
+  memset(&d, 0, sizeof(d));
+  d.dtype = c->dtype; d.ks = 3; d.N = c->N; d.H = c->H; d.W = c->W; d.Cout = c->C; d.alpha = 1.f;
+  d.nsrc = 1; d.src_ps[0] = c->C; d.src_ch[0] = c->C; d.out_ps = c->C; d.cout_tiles = c->cout_tiles; d.deep = c->deep; d.mt = 1;
+}
+
+extern "C" int vmg_resblock_chain_fwd(const vmg_chain_desc* c, void* stream) {
+  VMG_CHECK(c && c->nblk >= 0 && c->nsrc >= 1 && c->nsrc <= 4 && c->y && c->packed0, "resblock_chain_fwd: bad descriptor");
+  VMG_CHECK(c->nblk == 0 || (c->t && c->packed1 && c->packed2 && c->bias1 && c->bias2), "resblock_chain_fwd: null block arrays");
+  vmg_conv_desc d;
+  chain_base(c, d);
+  d.nsrc = c->nsrc;
+  for (int s = 0; s < c->nsrc; ++s) { d.src[s] = c->src[s]; d.src_ps[s] = c->src_ps[s]; d.src_ch[s] = c->src_ch[s]; }
+  d.packed = c->packed0; d.bias = c->bias0; d.out = c->y[0]; d.act = VMG_ACT_LRELU; d.slope = c->slope0;
+  d.cout_tiles = c->cout_tiles0; d.deep = c->deep0;
+  int rc = vmg_conv_fwd(&d, stream);
+  if (rc) return rc;
+  for (int k = 0; k < c->nblk; ++k) {
+    chain_base(c, d);
+    d.src[0] = c->y[k]; d.packed = c->packed1[k]; d.bias = c->bias1[k]; d.out = c->t[k]; d.act = VMG_ACT_RELU;
+    if ((rc = vmg_conv_fwd(&d, stream))) return rc;
+    chain_base(c, d);
+    d.src[0] = c->t[k]; d.packed = c->packed2[k]; d.bias = c->bias2[k]; d.out = c->y[k + 1]; d.alpha = c->r_scaling;
+    d.res = c->y[k]; d.res_ps = c->C;
+    if ((rc = vmg_conv_fwd(&d, stream))) return rc;
+  }
+  return 0;
+}
+
+extern "C" int vmg_resblock_chain_bwd(const vmg_chain_desc* c, void* stream) {
+  VMG_CHECK(c && c->nblk >= 0 && c->g_y, "resblock_chain_bwd: bad descriptor");
+  VMG_CHECK(c->nblk == 0 || (c->t && c->g_t && c->packed1 && c->packed2), "resblock_chain_bwd: null block arrays");
+  vmg_conv_desc d;
+  for (int k = c->nblk - 1; k >= 0; --k) {
+    // g_t[k] = r * dgrad2(g_y[k+1]) * relu'(t_k)
+    chain_base(c, d);
+    d.src[0] = c->g_y[k + 1]; d.packed = c->packed2[k]; d.out = c->g_t[k]; d.alpha = c->r_scaling; d.aux = c->t[k]; d.aux_ps = c->C; d.actgrad = 1;
+    int rc = vmg_conv_fwd(&d, stream);
+    if (rc) return rc;
+    // g_y[k] = g_y[k+1] + dgrad1(g_t[k])
+    chain_base(c, d);
+    d.src[0] = c->g_t[k]; d.packed = c->packed1[k]; d.out = c->g_y[k]; d.res = c->g_y[k + 1]; d.res_ps = c->C;
+    if ((rc = vmg_conv_fwd(&d, stream))) return rc;
+  }
+  return 0;
+}

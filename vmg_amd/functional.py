@@ -341,15 +341,12 @@ class _ResidualChain(torch.autograd.Function):
         src_ch = [t.shape[-1] for t in srcs]
         w0, b0 = params[0], params[1]
         C = w0.shape[0]
-        t0_, m0_, d0_ = choose_tiling(M, C, 3, dt, src_ch)
-        y, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=m0_, deep=d0_)
-        tiles, mt, deep = choose_tiling(M, C, 3, dt, [C])
-        saved = [y]
-        for k in range(nblk):
-            w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
-            t, _ = K.conv_forward([y], packed(w1, dt, "fwd", [C], tiles=tiles, deep=deep), b1, N, H, W, act=hip.ACT_RELU, mt=mt, deep=deep)
-            y, _ = K.conv_forward([t], packed(w2, dt, "fwd", [C], tiles=tiles, deep=deep), b2, N, H, W, alpha=r_scaling, res=y, mt=mt, deep=deep)
-            saved += [t, y]
+        t0_, _, d0_ = choose_tiling(M, C, 3, dt, src_ch)
+        tiles, _, deep = choose_tiling(M, C, 3, dt, [C])
+        pw1 = [packed(params[2 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
+        pw2 = [packed(params[4 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
+        ys, ts = K.resblock_chain_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, 0.1, d0_, pw1,
+                                          [params[3 + 4 * k] for k in range(nblk)], pw2, [params[5 + 4 * k] for k in range(nblk)], r_scaling, deep)
         ctx.meta = (r_scaling, nsrc, nblk, N, H, W, src_ch, C)
         ctx.wgrad = any(ctx.needs_input_grad[2 + nsrc:])
         ctx.defer = ctx.wgrad and DEFERRED.mode == "deferred"
@@ -357,35 +354,35 @@ class _ResidualChain(torch.autograd.Function):
             for p, pb in zip(params[0::2], params[1::2]):
                 ctx.gen = DEFERRED.note_use(p, pb)
         ctx.params = params
-        ctx.save_for_backward(*srcs, *saved[:-1])  # the final output is not needed
-        return y
+        ctx.save_for_backward(*srcs, *ys[:max(nblk, 1)], *ts)  # the final output is not needed (with no blocks y_0 is the output)
+        return ys[-1]
 
     @staticmethod
     def backward(ctx, g):
         r, nsrc, nblk, N, H, W, src_ch, C = ctx.meta
         params = ctx.params
         srcs = list(ctx.saved_tensors[:nsrc])
-        saved = list(ctx.saved_tensors[nsrc:])  # y0, t0, y1, t1, ..., y_{nblk-1}, t_{nblk-1}   (y_nblk dropped)
-        g = g.contiguous()
+        ys = list(ctx.saved_tensors[nsrc:nsrc + max(nblk, 1)])  # y_0 .. y_{nblk-1}
+        ts = list(ctx.saved_tensors[nsrc + max(nblk, 1):])      # t_0 .. t_{nblk-1}
+        y0 = ys[0]
         dt = g.dtype
         M = N * H * W
         tiles, mt, deep = choose_tiling(M, C, 3, dt, [C])
         pg = [None] * len(params)  # parameter gradients returned through autograd (mode 'autograd')
+        pd1 = [packed(params[2 + 4 * k], dt, "dgrad", None, 0, C, tiles=tiles, deep=deep) for k in range(nblk)]
+        pd2 = [packed(params[4 + 4 * k], dt, "dgrad", None, 0, C, tiles=tiles, deep=deep) for k in range(nblk)]
+        gys, gts = K.resblock_chain_backward(g, ts, pd1, pd2, r, deep)
         for k in range(nblk - 1, -1, -1):
             w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
-            yk, tk = saved[2 * k], saved[2 * k + 1]
-            # d t_k = r * dgrad2(g) masked by relu'(t_k)
-            dt_k, _ = K.conv_forward([g], packed(w2, dt, "dgrad", None, 0, C, tiles=tiles, deep=deep), None, N, H, W, alpha=r, aux=tk, actgrad=1, mt=mt, deep=deep)
             if ctx.defer:
-                DEFERRED.add(w2, b2, [tk], [C], g, 3, N, H, W, scale=r, gen=ctx.gen)
-                DEFERRED.add(w1, b1, [yk], [C], dt_k, 3, N, H, W, gen=ctx.gen)
+                DEFERRED.add(w2, b2, [ts[k]], [C], gys[k + 1], 3, N, H, W, scale=r, gen=ctx.gen)
+                DEFERRED.add(w1, b1, [ys[k]], [C], gts[k], 3, N, H, W, gen=ctx.gen)
             elif ctx.wgrad:
-                pg[4 + 4 * k], pg[5 + 4 * k] = _wgrad_now(w2, True, [tk], [C], g, 3, N, H, W, scale=r)
-                pg[2 + 4 * k], pg[3 + 4 * k] = _wgrad_now(w1, True, [yk], [C], dt_k, 3, N, H, W)
-            # d y_k = g + dgrad1(d t_k)
-            g, _ = K.conv_forward([dt_k], packed(w1, dt, "dgrad", None, 0, C, tiles=tiles, deep=deep), None, N, H, W, res=g, mt=mt, deep=deep)
+                pg[4 + 4 * k], pg[5 + 4 * k] = _wgrad_now(w2, True, [ts[k]], [C], gys[k + 1], 3, N, H, W, scale=r)
+                pg[2 + 4 * k], pg[3 + 4 * k] = _wgrad_now(w1, True, [ys[k]], [C], gts[k], 3, N, H, W)
+        g = gys[0]
         w0, b0 = params[0], params[1]
-        dpre0 = K.act_backward(g, saved[0], hip.ACT_LRELU, 0.1, 1.0)
+        dpre0 = K.act_backward(g, y0, hip.ACT_LRELU, 0.1, 1.0)
         d_srcs = []
         off = 0
         for i, c in enumerate(src_ch):

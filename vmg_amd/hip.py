@@ -37,6 +37,18 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class ChainDesc(ctypes.Structure):
+    """vmg_chain_desc (include/vmg_hip.h)."""
+    _fields_ = [
+        ("dtype", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("nblk", c_int), ("nsrc", c_int),
+        ("src", c_void_p * 4), ("src_ps", c_int64 * 4), ("src_ch", c_int * 4),
+        ("packed0", c_void_p), ("bias0", c_void_p), ("slope0", c_float), ("cout_tiles0", c_int), ("deep0", c_int),
+        ("packed1", POINTER(c_void_p)), ("bias1", POINTER(c_void_p)), ("packed2", POINTER(c_void_p)), ("bias2", POINTER(c_void_p)),
+        ("r_scaling", c_float), ("cout_tiles", c_int), ("deep", c_int),
+        ("y", POINTER(c_void_p)), ("t", POINTER(c_void_p)), ("g_y", POINTER(c_void_p)), ("g_t", POINTER(c_void_p)),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol of include/vmg_hip.h must be listed (tests/test_abi.py checks)
@@ -50,6 +62,8 @@ SIGNATURES = {
     "vmg_convws_pack_bytes": (c_int64, [c_int, c_int, POINTER(c_int), c_int]),
     "vmg_convws_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_void_p, c_void_p]),
     "vmg_conv_fwd": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "vmg_resblock_chain_fwd": (c_int, [POINTER(ChainDesc), c_void_p]),
+    "vmg_resblock_chain_bwd": (c_int, [POINTER(ChainDesc), c_void_p]),
     "vmg_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_void_p]),
     "vmg_pixel_shuffle": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_layernorm_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

@@ -222,6 +222,67 @@ def conv_forward(srcs: Sequence[torch.Tensor], pw: PackedConv, bias: Optional[to
     return out, out_pre
 
 
+def _parr(ts):
+    return (ctypes.c_void_p * max(1, len(ts)))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: torch.Tensor, slope0: float, deep0: int, pw1: Sequence[PackedConv],
+                           b1: Sequence[torch.Tensor], pw2: Sequence[PackedConv], b2: Sequence[torch.Tensor], r_scaling: float, deep: int):
+    """ResidualBlocksWithInputConv forward as ONE C call (vmg_resblock_chain_fwd).  Returns (ys, ts): nblk + 1 block outputs and nblk
+    ReLU outputs, all (N, H, W, C)."""
+    x0 = srcs[0]
+    hip.require_cuda(*srcs, b0, *b1, *b2)
+    N, H, W = x0.shape[0], x0.shape[1], x0.shape[2]
+    M = N * H * W
+    C, nblk, dt = pw0.cout, len(pw1), x0.dtype
+    if len(srcs) != len(pw0.src_ch) or any(s.dtype != dt or s.shape[-1] != c or s.numel() // s.shape[-1] != M for s, c in zip(srcs, pw0.src_ch)):
+        raise HipError("resblock_chain: sources do not match conv0's pack")
+    if any(p.cout != C or p.src_ch != [C] or p.dtype != dt or p.layout != pw1[0].layout or p.cout_tiles != pw1[0].cout_tiles for p in list(pw1) + list(pw2)) or \
+            pw0.dtype != dt or len(pw2) != nblk or len(b1) != nblk or len(b2) != nblk:
+        raise HipError("resblock_chain: block packs must be C -> C packs of one layout")
+    for b in [b0] + list(b1) + list(b2):
+        if b.dtype != torch.float32 or b.numel() != C or not b.is_contiguous():
+            raise HipError("resblock_chain: biases must be contiguous fp32 of length C")
+    ys = [torch.empty((N, H, W, C), dtype=dt, device=x0.device) for _ in range(nblk + 1)]
+    ts = [torch.empty((N, H, W, C), dtype=dt, device=x0.device) for _ in range(nblk)]
+    d = hip.ChainDesc()
+    d.dtype, d.N, d.H, d.W, d.C, d.nblk, d.nsrc = hip.dtype_code(dt), N, H, W, C, nblk, len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i], d.src_ps[i], d.src_ch[i] = s.data_ptr(), _pix_stride(s), pw0.src_ch[i]
+    d.packed0, d.bias0, d.slope0 = pw0.buf.data_ptr(), b0.data_ptr(), slope0
+    d.cout_tiles0, d.deep0 = pw0.cout_tiles, 3 if pw0.layout == "ws" else deep0
+    keep = [_parr([p.buf for p in pw1]), _parr(list(b1)), _parr([p.buf for p in pw2]), _parr(list(b2)), _parr(ys), _parr(ts)]
+    d.packed1, d.bias1, d.packed2, d.bias2, d.y, d.t = keep
+    d.r_scaling = r_scaling
+    d.cout_tiles = pw1[0].cout_tiles if nblk else pw0.cout_tiles
+    d.deep = (3 if pw1[0].layout == "ws" else deep) if nblk else 0
+    hip.check(hip.lib().vmg_resblock_chain_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_resblock_chain_fwd")
+    return ys, ts
+
+
+def resblock_chain_backward(g: torch.Tensor, ts: Sequence[torch.Tensor], pd1: Sequence[PackedConv], pd2: Sequence[PackedConv], r_scaling: float,
+                            deep: int):
+    """Data-gradient sweep of the residual blocks (vmg_resblock_chain_bwd).  g: gradient of the chain output; pd1 / pd2: data-gradient
+    packs of conv1 / conv2 per block.  Returns (g_ys, g_ts): g_ys[k] = gradient of y_k (g_ys[nblk] is g), g_ts[k] of conv1_k's pre-activation."""
+    hip.require_cuda(g, *ts)
+    nblk = len(ts)
+    N, H, W, C = g.shape
+    g = g.contiguous()
+    gys = [torch.empty_like(g) for _ in range(nblk)] + [g]
+    gts = [torch.empty_like(g) for _ in range(nblk)]
+    if nblk == 0:
+        return gys, gts
+    d = hip.ChainDesc()
+    d.dtype, d.N, d.H, d.W, d.C, d.nblk, d.nsrc = hip.dtype_code(g.dtype), N, H, W, C, nblk, 1
+    keep = [_parr([p.buf for p in pd1]), _parr([p.buf for p in pd2]), _parr(list(ts)), _parr(gys), _parr(gts)]
+    d.packed1, d.packed2, d.t, d.g_y, d.g_t = keep
+    d.r_scaling = r_scaling
+    d.cout_tiles = pd1[0].cout_tiles
+    d.deep = 3 if pd1[0].layout == "ws" else deep
+    hip.check(hip.lib().vmg_resblock_chain_bwd(ctypes.byref(d), hip.stream_ptr()), "vmg_resblock_chain_bwd")
+    return gys, gts
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], ks: int, N: int, H: int,
                W: int, scale: float = 1.0, o0: int = 0, i0: int = 0):
     """dW (fp32, (O_total, I_total, ks, ks) or (O_total, I_total)) += scale * wgrad(x, dy); db += scale * sum(dy).
