@@ -278,6 +278,19 @@ int vmg_prof_select_pixels(vmg_ctx* ctx, int64_t pixels);
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);
 
+/* ---- 3-D shifted-window attention (reference: models/swin_3d.py:167-252 rWindowAttention.attention, :55-118 window partition / mask, :772-832 block) ----
+ * q (B, D, H, W, C) and kv (B, D, H, W, 2C; k then v) are the outputs of the q / kv Linears on the UN-partitioned feature map; window partition
+ * into (wt, 8, 8) windows, the zero padding to window multiples (a padded position holds the Linear's bias bq / bkv, as in the reference where
+ * zeros are padded before the Linears; pass null for bias-free Linears), the cyclic roll by (sd, sh, sw) of shifted blocks, the -100 region mask
+ * and the relative-position bias gather (table (n_rel, heads) for the (wt, 8, 8) window) are index arithmetic inside the kernel.  Every time
+ * slice's queries attend to the tokens of the other slices of their window.  out (B, D, H, W, C); lse (windows, heads, wt*64) fp32 is kept for the
+ * backward, which writes dq, dkv and accumulates (+=) dtable and, for gradient reaching the biases through padded positions, dbq / dbkv (may be null). */
+int vmg_win3d_attn_fwd(int dtype, const void* q, const void* kv, const float* bq, const float* bkv, const float* table, void* out, float* lse,
+                       int B, int D, int H, int W, int C, int heads, int wt, int sd, int sh, int sw, void* stream);
+int vmg_win3d_attn_bwd(int dtype, const void* q, const void* kv, const float* bq, const float* bkv, const float* table, const void* out,
+                       const float* lse, const void* d_out, void* dq, void* dkv, float* dtable, float* dbq, float* dbkv, int B, int D, int H, int W,
+                       int C, int heads, int wt, int sd, int sh, int sw, void* stream);
+
 /* ---- multi-scale skip (MDSC; reference: models/vmg.py:388-400, 519, 525): adaptive_max_pool2d to (H/f, W/f) as non-overlapping f x f
  * windows (f must divide H and W; f = 4 in the model).  idx (N, H/f, W/f, C) bytes: position of the winner inside its window.
  * The 1x1 conv that follows is vmg_conv_fwd (KS = 1); GroupNorm(1, C) + ReLU is two vmg_group_reduce calls (sum, sum of squares) and

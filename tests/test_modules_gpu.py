@@ -150,3 +150,44 @@ def test_mdsc_skip_fwd_bwd(dtype):
     for k, gw in zip(sorted(osd), wg[1:]):
         err = float((params[k].grad.cpu().reshape(gw.shape) - gw).abs().max())
         assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["swin_w2_t5", "swin_w4_t7"])
+def test_swin_decoder_layer_fwd_bwd(name, dtype):
+    """swin_3d.DecoderLayer (two blocks, the second shifted) through the product: the window attention kernel folds partition, the
+    zero padding (20 x 20 -> 24 x 24 in swin_w2_t5), the roll, the -100 mask and the bias gather into its addressing; T = 5 / 7 exercise
+    the frame repetition.  Forward vs the oracle and the reference fixture; input and parameter gradients vs the oracle's autograd."""
+    from oracle import cases as C, recipe as R, vmg_oracle as O
+    from vmg_amd.model import DecoderLayer
+    case = C.CASES[name]
+    shapes, ref_outs = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+    sd = C.case_state_dict(case, shapes)
+    ws = case["window_of"]("")
+    heads = 4 if name == "swin_w2_t5" else 8
+    x = case["inputs"]()["x"]
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.swin_decoder_layer(osd, "", xo, heads, ws)
+    go = R.seeded(tuple(want.shape), 96)
+    if dtype == torch.bfloat16:
+        go = go.to(dtype).float()
+    leaves = [k for k in sorted(osd) if osd[k].dtype.is_floating_point]
+    wg = torch.autograd.grad(want, [xo] + [osd[k] for k in leaves], go)
+    m = DecoderLayer(32, 2, heads, list(ws), 2, True).cuda()
+    m.load_state_dict(sd, strict=True)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    got = m(xd)
+    got.backward(go.cuda().to(dtype))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got.float().cpu() - want).abs().max()) <= tol * scale
+    if dtype == torch.float32:
+        assert float(np.abs(C.subsample(got.float().cpu()) - ref_outs[0]["sub"]).max()) <= tol * scale
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= tol * max(1.0, float(wg[0].abs().max()))
+    params = dict(m.named_parameters())
+    for k, gw in zip(leaves, wg[1:]):
+        err = float((params[k].grad.cpu() - gw).abs().max())
+        assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"

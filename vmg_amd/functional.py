@@ -787,67 +787,28 @@ def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: in
     return _LTAM.apply(q, loc, rpe, decay_v, (heads, wh, ww, float(scale)), *keys, *vals)
 
 
-# ---- 3-D shifted windows (models/swin_3d.py) ----------------------------------------------------------
-def window_partition(y: torch.Tensor, ws, ss, pads):
-    """zero-pad (D,H,W) by pads, roll by -ss, cut into (wt,wh,ww) windows -> (B*nW, N, C) (swin_3d.py:55-68, 786-797)."""
-    B, D, H, W, C = y.shape
-    pd, pb, pr = pads
-    y = F.pad(y, (0, 0, 0, pr, 0, pb, 0, pd))
-    _, Dp, Hp, Wp, _ = y.shape
-    if any(s > 0 for s in ss):
-        y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-    yw = y.reshape(B, Dp // ws[0], ws[0], Hp // ws[1], ws[1], Wp // ws[2], ws[2], C)
-    yw = yw.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, ws[0] * ws[1] * ws[2], C).contiguous()
-    return yw, (B, D, H, W, Dp, Hp, Wp, tuple(ws), tuple(ss))
+# ---- 3-D shifted-window attention (models/swin_3d.py) --------------------------------------------------
+class _Win3dAttention(torch.autograd.Function):
+    """rWindowAttention.attention for every window / head / time slice (swin_3d.py:167-252) with window partition, roll, padding,
+    mask and bias gather folded into the kernel's addressing (vmg_win3d_attn_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, bq, bkv, table, heads, wt, shift):
+        q, kv = q.contiguous(), kv.contiguous()
+        tab = table.detach().contiguous()
+        out, lse = K.win3d_attn_forward(q, kv, bq, bkv, tab, heads, wt, shift)
+        ctx.cfg = (heads, wt, shift)
+        ctx.save_for_backward(q, kv, bq, bkv, tab, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, bq, bkv, tab, out, lse = ctx.saved_tensors
+        heads, wt, shift = ctx.cfg
+        dq, dkv, dtable, dbq, dbkv = K.win3d_attn_backward(q, kv, bq, bkv, tab, out, lse, dout, heads, wt, shift)
+        return dq, dkv, dbq, dbkv, dtable, None, None, None
 
 
-def window_reverse(aw: torch.Tensor, meta) -> torch.Tensor:
-    B, D, H, W, Dp, Hp, Wp, ws, ss = meta
-    y = aw.reshape(B, Dp // ws[0], Hp // ws[1], Wp // ws[2], ws[0], ws[1], ws[2], -1)
-    y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, Dp, Hp, Wp, -1)
-    if any(s > 0 for s in ss):
-        y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
-    return y[:, :D, :H, :W].contiguous()
-
-
-def shift_mask(D, H, W, ws, ss, device) -> torch.Tensor:
-    """(nW, N, N) of 0 / -100 (swin_3d.py:104-118)."""
-    img = torch.zeros(1, D, H, W, 1, device=device)
-    cnt = 0
-    for d in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
-        for h in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
-            for w in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
-                img[:, d, h, w, :] = cnt
-                cnt += 1
-    mw, _ = window_partition(img, ws, (0, 0, 0), (0, 0, 0))
-    mw = mw.squeeze(-1)
-    diff = mw[:, None, :] - mw[:, :, None]
-    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
-
-
-def window_cross_slice_attention(q, kv, table, index, mask, heads: int, ws_cfg):
-    """rWindowAttention.attention for every time slice of the window (swin_3d.py:167-252): queries of slice i
-    attend to the N - interval tokens of the other slices; bias gathered from the relative-position table."""
-    B_, N, C = q.shape
-    d = C // heads
-    scale = d ** -0.5
-    interval = ws_cfg[1] * ws_cfg[2]
-    total = ws_cfg[0] * interval
-    qh = q.reshape(B_, N, heads, d).permute(0, 2, 1, 3).float()
-    kvh = kv.reshape(B_, N, 2, heads, d).permute(2, 0, 3, 1, 4).float()
-    k, v = kvh[0], kvh[1]
-    nsl = len(range(0, total, interval))
-    outs = []
-    for i in range(nsl):
-        lo = i * interval
-        hi = total if i == nsl - 1 else (i + 1) * interval
-        other = [s for s in range(total) if s < lo or s >= hi]
-        attn = (qh[:, :, lo:hi] * scale) @ k[:, :, other].transpose(-2, -1)
-        bias = table[index[lo:hi][:, other].reshape(-1)].reshape(hi - lo, len(other), heads).permute(2, 0, 1)
-        attn = attn + bias[None]
-        if mask is not None:
-            nW = mask.shape[0]
-            attn = attn.reshape(B_ // nW, nW, heads, hi - lo, len(other)) + mask[:, lo:hi][:, :, other][None, :, None]
-            attn = attn.reshape(-1, heads, hi - lo, len(other))
-        outs.append((attn.softmax(-1) @ v[:, :, other]).transpose(1, 2).reshape(B_, hi - lo, C))
-    return torch.cat(outs, 1).to(q.dtype).contiguous()
+def win3d_attention(q: torch.Tensor, kv: torch.Tensor, bq, bkv, table: torch.Tensor, heads: int, wt: int, shift) -> torch.Tensor:
+    """q (B,D,H,W,C), kv (B,D,H,W,2C): outputs of the q / kv Linears on the un-partitioned feature map -> (B,D,H,W,C)."""
+    return _Win3dAttention.apply(q, kv, bq, bkv, table, int(heads), int(wt), tuple(int(v) for v in shift))

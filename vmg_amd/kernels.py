@@ -369,6 +369,41 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
     return dx, dw, db
 
 
+def _win3d_geom(q, kv, table, heads, wt):
+    B, D, H, W, C = q.shape
+    if tuple(kv.shape) != (B, D, H, W, 2 * C) or kv.dtype != q.dtype or not q.is_contiguous() or not kv.is_contiguous():
+        raise HipError("win3d_attn: contiguous q (B,D,H,W,C) and kv (B,D,H,W,2C) of one dtype expected")
+    if table.dtype != torch.float32 or not table.is_contiguous() or tuple(table.shape) != ((2 * wt - 1) * 225, heads):
+        raise HipError(f"win3d_attn: the bias table must be contiguous fp32 ((2*{wt}-1)*225, {heads})")
+    nwin = B * ((D + wt - 1) // wt) * ((H + 7) // 8) * ((W + 7) // 8)
+    return B, D, H, W, C, nwin
+
+
+def win3d_attn_forward(q, kv, bq, bkv, table, heads: int, wt: int, shift):
+    hip.require_cuda(q, kv, bq, bkv, table)
+    B, D, H, W, C, nwin = _win3d_geom(q, kv, table, heads, wt)
+    out = torch.empty_like(q)
+    lse = torch.empty((nwin, heads, wt * 64), dtype=torch.float32, device=q.device)
+    pz = lambda t: t.data_ptr() if t is not None else None
+    hip.check(hip.lib().vmg_win3d_attn_fwd(hip.dtype_code(q.dtype), q.data_ptr(), kv.data_ptr(), pz(bq), pz(bkv), table.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                           B, D, H, W, C, heads, wt, shift[0], shift[1], shift[2], hip.stream_ptr()), "vmg_win3d_attn_fwd")
+    return out, lse
+
+
+def win3d_attn_backward(q, kv, bq, bkv, table, out, lse, dout, heads: int, wt: int, shift):
+    B, D, H, W, C, nwin = _win3d_geom(q, kv, table, heads, wt)
+    dout = dout.contiguous()
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dtable = torch.zeros_like(table)
+    dbq = torch.zeros(C, dtype=torch.float32, device=q.device) if bq is not None else None
+    dbkv = torch.zeros(2 * C, dtype=torch.float32, device=q.device) if bkv is not None else None
+    pz = lambda t: t.data_ptr() if t is not None else None
+    hip.check(hip.lib().vmg_win3d_attn_bwd(hip.dtype_code(q.dtype), q.data_ptr(), kv.data_ptr(), pz(bq), pz(bkv), table.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                           dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dtable.data_ptr(), pz(dbq), pz(dbkv), B, D, H, W, C, heads, wt,
+                                           shift[0], shift[1], shift[2], hip.stream_ptr()), "vmg_win3d_attn_bwd")
+    return dq, dkv, dtable, dbq, dbkv
+
+
 def maxpool_forward(x: torch.Tensor, f: int):
     """Non-overlapping f x f max pooling of a contiguous channels-last (n,h,w,c) tensor -> (y, idx)."""
     hip.require_cuda(x)

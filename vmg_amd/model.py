@@ -426,12 +426,12 @@ class rWindowAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
-    def forward(self, xw, mask):
-        q = lin(self.q, xw)
-        kv = lin(self.kv, xw)
-        o = FH.window_cross_slice_attention(q, kv, self.relative_position_bias_table, self.relative_position_index, mask,
-                                            self.num_heads, self.window_size)
-        return lin(self.proj, o)
+    def forward(self, y, shift):
+        """y (B,D,H,W,C): the normalised, UN-partitioned feature map; shift: the block's (sd, sh, sw) (zeros when not shifted)."""
+        q = lin(self.q, y)
+        kv = lin(self.kv, y)
+        o = FH.win3d_attention(q, kv, self.q.bias, self.kv.bias, self.relative_position_bias_table, self.num_heads, self.window_size[0], shift)
+        return o
 
 
 class EncoderBlockOnOnetoken(nn.Module):
@@ -443,18 +443,14 @@ class EncoderBlockOnOnetoken(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x, mask_full):
+    def forward(self, x):
         B, D, H, W, C = x.shape
         ws, ss = _get_window_size((D, H, W), self.window_size, self.shift_size)
+        if tuple(ws) != (self.window_size[0], 8, 8):
+            raise HipError(f"3-D window attention: the feature map {(D, H, W)} must be at least one (wt, 8, 8) window ({self.window_size})")
         y = lnorm(self.norm1, x)
-        pd = (ws[0] - D % ws[0]) % ws[0]
-        pb = (ws[1] - H % ws[1]) % ws[1]
-        pr = (ws[2] - W % ws[2]) % ws[2]
-        shifted = any(s > 0 for s in ss)
-        yw, meta = FH.window_partition(y, ws, ss if shifted else (0, 0, 0), (pd, pb, pr))
-        aw = self.attn(yw, mask_full if shifted else None)
-        y = FH.window_reverse(aw, meta)
-        x = x + y
+        # window partition, padding, roll and mask live in the attention kernel's addressing; proj adds the residual in its epilogue
+        x = lin(self.attn.proj, self.attn(y, ss), res=x)
         z = lnorm(self.norm2, x)
         return lin(self.mlp.fc2, lin(self.mlp.fc1, z, act=ACT_GELU), res=x)
 
@@ -483,11 +479,8 @@ class DecoderLayer(nn.Module):
             rep = [start[i] for i in delta]
             x = torch.cat([x, x[:, rep]], 1)[:, new_seq].contiguous()
             D = x.shape[1]
-        ws, ss = _get_window_size((D, H, W), self.window_size, self.shift_size)
-        Dp, Hp, Wp = (int(np.ceil(v / w)) * w for v, w in zip((D, H, W), ws))
-        mask = FH.shift_mask(Dp, Hp, Wp, ws, ss, x.device)
         for blk in self.blocks:
-            x = blk(x, mask)
+            x = blk(x)
         if seq_back is not None:
             x = x[:, seq_back].contiguous()
         return x
