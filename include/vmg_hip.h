@@ -278,6 +278,17 @@ int vmg_prof_select_pixels(vmg_ctx* ctx, int64_t pixels);
  * above contain on top of the kernel's own duration (synchronises; call outside the timed region). */
 double vmg_prof_null_interval_us(int reps, void* stream);
 
+/* ---- MorphFC H- / W-branch (reference: Enhanced_MorphFCs_decay.forward, models/function.py:763-786), bf16 --------------------------------------
+ * out = reshuffle^-1( act( reshuffle(x) W^T + b ) ) * out_scale with the token reshuffle (pad C -> Cp and the mixed axis to a multiple of `chunk`;
+ * token (group, k) feature p*S + s <- position p of the group, channel k*S + s; S = Cp / chunk) folded into the GEMM's operand addressing: x, out
+ * are the channels-last (BT, H, W, C) feature maps, no token tensor exists.  axis 0 mixes along H, 1 along W.  `packed`: vmg_conv_pack image of
+ * the (Cp, Cp) weight (ks = 1, one source of Cp channels, cout_tiles = ceil(Cp / 16)); the caller packs AFTER applying the retention decay
+ * W <- W * Gamma (function.py:766-768).  relu_mask (may be null): the data-gradient form -- x is multiplied by (relu_mask > 0) * in_scale on the way
+ * in (relu_mask = the forward output, `packed` = the data-gradient pack, relu = 0).  chunk must divide 16; Cp in {144, 112, 64, 32, 16}; other
+ * shapes (e.g. Cp = 228, chunk 12 of the full configuration) take the general path: gather kernel + vmg_conv_fwd. */
+int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, int BT, int H, int W,
+                    int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream);
+
 /* ---- 3-D shifted-window attention (reference: models/swin_3d.py:167-252 rWindowAttention.attention, :55-118 window partition / mask, :772-832 block) ----
  * q (B, D, H, W, C) and kv (B, D, H, W, 2C; k then v) are the outputs of the q / kv Linears on the UN-partitioned feature map; window partition
  * into (wt, 8, 8) windows, the zero padding to window multiples (a padded position holds the Linear's bias bq / bkv, as in the reference where

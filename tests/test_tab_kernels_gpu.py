@@ -95,3 +95,37 @@ def test_residual_drop_path(dtype):
     assert torch.equal(res.grad, dy)
     m = ratio.reshape(B, -1).median(1).values.reshape(B, 1, 1, 1, 1)
     assert float((y.grad.float() - dy.float() * m).abs().max()) <= 5 * tol * max(1.0, float(dy.abs().max())) + 1e-3
+
+
+@pytest.mark.parametrize("cfg", [(144, 8, 24, 20), (144, 16, 20, 36), (112, 8, 16, 16), (16, 8, 12, 10), (32, 16, 40, 24), (64, 8, 8, 8)])
+@pytest.mark.parametrize("axis", ["h", "w"])
+def test_fused_morphfc_branch_fwd_bwd(cfg, axis):
+    """vmg_morphfc_fwd (token reshuffle inside the GEMM addressing) vs the oracle's restatement of the reference lines (pad, reshuffle,
+    Linear + ReLU, / Cp, inverse reshuffle, crop; models/function.py:763-786): output, input gradient, weight / bias gradients.  Sizes
+    that are no multiple of the chunk exercise the padded positions; bf16 tolerance as for the convs (inputs / weights pre-rounded)."""
+    import math
+    import torch.nn.functional as F
+    from oracle import recipe as R, vmg_oracle as O
+    from vmg_amd import functional as FH, kernels as K
+    C, chunk, H, W = cfg
+    Cp = int(math.ceil(C / chunk)) * chunk
+    dt = torch.bfloat16
+    x = _q(R.seeded((2, 3, H, W, C), 110), dt)
+    w = _q(R.seeded((Cp, Cp), 111, Cp ** -0.5), dt)
+    b = R.seeded((Cp,), 112, 0.1)
+    go = _q(R.seeded((2, 3, H, W, C), 113), dt)
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    t = O.morph_tokens(xo, axis, chunk, Cp)
+    want = O.morph_untokens(F.relu(F.linear(t, wo, bo)) / Cp, axis, chunk, Cp, H, W, C)
+    wg = torch.autograd.grad(want, [xo, wo, bo], go)
+    assert K.morph_fused_ok(x.cuda().to(dt), chunk, Cp)
+    xd = x.cuda().to(dt).requires_grad_(True)
+    wd = torch.nn.Parameter(w.cuda())
+    bd = torch.nn.Parameter(b.cuda())
+    got = FH.morph_linear(xd, wd, bd, axis, chunk, Cp)
+    got.backward(go.cuda().to(dt))
+    sc = max(1e-3, float(want.abs().max()))
+    assert float((got.float().cpu() - want).abs().max()) <= 2e-2 * sc
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= 3e-2 * max(1e-6, float(wg[0].abs().max()))
+    assert float((wd.grad.cpu() - wg[1]).abs().max()) <= 3e-2 * max(1e-6, float(wg[1].abs().max()))
+    assert float((bd.grad.cpu() - wg[2]).abs().max()) <= 3e-2 * max(1e-6, float(wg[2].abs().max()))

@@ -1,0 +1,211 @@
+// H- / W-branch of the MorphFC token mixer (reference: Enhanced_MorphFCs_decay.forward, models/function.py:763-786) with the token
+// reshuffle folded into the GEMM's operand addressing: no token tensor is materialised on either side.
+//
+// The reference pads C -> Cp = chunk * S and the mixed axis to a multiple of `chunk`, takes `chunk` consecutive positions of the axis
+// as a GROUP and turns it into `chunk` tokens: token (group, k) has features f = p*S + s <- x[position p of the group][channel k*S + s]
+// (a transpose of (p, k) with S-channel vectors as elements -- S = 18 or 9 channels: neither 16-byte nor 4-byte granular), applies
+// Linear(Cp, Cp) (+ ReLU, / Cp) and reshuffles back.  Here a wave owns a TILE of 16 tokens = 16 / chunk groups:
+//   1. the groups' pixels (chunk pixels x C channels each, contiguous rows of the channels-last feature map) are copied into a
+//      wave-private LDS block as they lie in HBM, 16 bytes per lane (zero rows / channels for the padding); in the data-gradient
+//      form the ReLU mask of the forward output and the 1/Cp scale are applied on the way in;
+//   2. the MFMA operand fragments (8 consecutive features of a token) are gathered from that block element by element
+//      (ds_read_u16: a fragment crosses positions when S is not a multiple of 8);
+//   3. weights (packed like a 1x1 convolution) are staged ONCE per workgroup in LDS and shared by its 8 waves;
+//   4. bias / ReLU / scale, then the results are scattered element-wise into a second LDS block in PIXEL layout and leave as
+//      whole 16-byte vectors of the output feature map (cropped to the real positions / channels).
+// HBM-bound: one read of x and one write of the branch output, 2*N*C*2 bytes; the gather / scatter is LDS traffic.
+#include "common.h"
+
+namespace {
+
+constexpr int MF_WAVES = 8;
+
+struct MorphK {
+  const bf16* x;      // (BT, H, W, C)
+  const bf16* mask;   // data-gradient form: the forward output h (same layout); x is multiplied by (mask > 0) * in_scale
+  bf16* out;          // (BT, H, W, C)
+  const char* wpack;  // vmg_conv_pack image, ks = 1, one source of Cp channels, NCT tiles
+  const float* bias;  // (Cp) or null
+  int BT, H, W, C, Cp, chunk, S, axis;  // axis 0: groups along H, 1: along W
+  int gpl;            // groups per line (= ceil(axis length / chunk))
+  long long ngroups;  // BT * lines * gpl
+  long long ntiles;
+  int relu;
+  float in_scale, out_scale;
+  int ss;             // stage stride of the pack (bytes)
+};
+
+template <int NK, int NCT>
+__global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const MorphK a) {
+  constexpr int COB = NCT * 16, KSB = 4 * COB * 16;  // bytes of one k-step of the pack
+  constexpr int NST = (NK + 1) / 2;                  // stages (two k-steps each) of the pack
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rowb = a.Cp * 2;                 // bytes of a pixel row in the LDS blocks
+  const int blkb = (16 * rowb + 15) & ~15;
+  char* wl = smem;                                    // [NST][ss]
+  char* xblk = smem + NST * a.ss + wave * 2 * blkb;   // [16 pixels][Cp] bf16
+  char* oblk = xblk + blkb;
+  // weights -> LDS, once
+  for (int i = tid * 16; i < NST * a.ss; i += MF_WAVES * 64 * 16) *reinterpret_cast<uint4*>(wl + i) = *reinterpret_cast<const uint4*>(a.wpack + i);
+  __syncthreads();
+
+  const int tok = lane & 15, kq = lane >> 4;
+  const int ch = a.chunk, S = a.S;
+  const int grp = tok / ch, kk = tok - grp * ch;  // this lane's token: group `grp` of the tile, channel chunk kk
+  // per k-step: (position, channel-in-chunk) of the first of the lane's 8 features
+  int p0[NK], s0[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const int f0 = 32 * ks + 8 * kq;
+    p0[ks] = f0 / S;
+    s0[ks] = f0 - p0[ks] * S;
+  }
+  const int vpp = a.C >> 3;      // 16-byte vectors per pixel (C % 8 == 0)
+  const int nvec = 16 * vpp;     // vectors of a tile's pixel block
+  const int G = 16 / ch;         // groups per tile
+  const long long lines_len = a.axis == 0 ? a.H : a.W;
+
+  for (long long tile = (long long)blockIdx.x * MF_WAVES + wave; tile < a.ntiles; tile += (long long)gridDim.x * MF_WAVES) {
+    // ---- 1. pixel block -> LDS (zero-filled padding)
+    for (int idx = lane; idx < nvec; idx += 64) {
+      const int pixl = idx / vpp, v = idx - pixl * vpp;
+      const int g = pixl / ch, p = pixl - g * ch;
+      const long long gg = tile * G + g;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (gg < a.ngroups) {
+        const int gi = (int)(gg % a.gpl);
+        long long r = gg / a.gpl;
+        const int line = (int)(r % (a.axis == 0 ? a.W : a.H));
+        const long long bt = r / (a.axis == 0 ? a.W : a.H);
+        const int pos = gi * ch + p;
+        if (pos < lines_len) {
+          const long long pix = a.axis == 0 ? (bt * a.H + pos) * a.W + line : (bt * a.H + line) * a.W + pos;
+          val = *reinterpret_cast<const uint4*>(a.x + pix * a.C + v * 8);
+          if (a.mask) {
+            const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + pix * a.C + v * 8);
+            bf16* e = reinterpret_cast<bf16*>(&val);
+            const bf16* m = reinterpret_cast<const bf16*>(&mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (float)m[j] > 0.f ? (bf16)((float)e[j] * a.in_scale) : (bf16)0.f;
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(xblk + pixl * rowb + v * 16) = val;
+    }
+    if (a.Cp > a.C) {  // padded channels read as zero
+      const int padc = a.Cp - a.C;
+      for (int idx = lane; idx < 16 * padc; idx += 64) {
+        const int pixl = idx / padc, c = a.C + idx - pixl * padc;
+        *reinterpret_cast<bf16*>(xblk + pixl * rowb + c * 2) = (bf16)0.f;
+      }
+    }
+    // (wave-private block: program order + hipcc's lgkmcnt waits are the only synchronisation needed)
+
+    // ---- 2./3. gather the token fragments, multiply
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      bf16x8 tf;
+      int p = p0[ks], s = s0[ks];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = p < ch;  // features >= Cp multiply zero weights
+        tf[j] = in ? *reinterpret_cast<const bf16*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : (bf16)0.f;
+        if (++s == S) { s = 0; ++p; }
+      }
+      const char* wk = wl + (ks >> 1) * a.ss + (ks & 1) * KSB + kq * (COB * 16) + tok * 16;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + ct * 256);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, tf, acc[ct], 0, 0, 0);
+      }
+    }
+    // ---- 4. epilogue: lane holds output features f' = ct*16 + kq*4 + r of its token -> pixel (grp, p' = f'/S), channel kk*S + f'%S
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int f0 = ct * 16 + kq * 4;
+      int p = f0 / S, s = f0 - p * S;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (f0 + r < a.Cp) {
+          float v = acc[ct][r] + (a.bias ? a.bias[f0 + r] : 0.f);
+          if (a.relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<bf16*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = (bf16)(v * a.out_scale);
+        }
+        if (++s == S) { s = 0; ++p; }
+      }
+    }
+    for (int idx = lane; idx < nvec; idx += 64) {
+      const int pixl = idx / vpp, v = idx - pixl * vpp;
+      const int g = pixl / ch, p = pixl - g * ch;
+      const long long gg = tile * G + g;
+      if (gg >= a.ngroups) continue;
+      const int gi = (int)(gg % a.gpl);
+      long long r = gg / a.gpl;
+      const int line = (int)(r % (a.axis == 0 ? a.W : a.H));
+      const long long bt = r / (a.axis == 0 ? a.W : a.H);
+      const int pos = gi * ch + p;
+      if (pos >= lines_len) continue;
+      const long long pix = a.axis == 0 ? (bt * a.H + pos) * a.W + line : (bt * a.H + line) * a.W + pos;
+      *reinterpret_cast<uint4*>(a.out + pix * a.C + v * 8) = *reinterpret_cast<const uint4*>(oblk + pixl * rowb + v * 16);
+    }
+  }
+}
+
+}  // namespace
+
+// the stage stride vmg_conv_pack uses for ks = 1 (conv_igemm.hip: stage_stride(1, ntb, 16))
+static int morph_stage_stride(int nct) { return (2 * 4 * nct * 16 * 16 + 4095) / 4096 * 4096; }
+
+extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, int BT,
+                               int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream) {
+  VMG_CHECK(x && packed && out && BT > 0 && H > 0 && W > 0, "morphfc: bad arguments");
+  VMG_CHECK(axis == 0 || axis == 1, "morphfc: axis 0 (H) or 1 (W)");
+  VMG_CHECK(chunk > 0 && 16 % chunk == 0 && Cp % chunk == 0 && Cp >= C && C % 8 == 0, "morphfc: chunk must divide 16 and Cp; C a multiple of 8");
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)relu_mask) % 16 == 0, "morphfc: pointers must be 16-byte aligned");
+  const int nk = (Cp + 31) / 32, nct = (Cp + 15) / 16;
+  VMG_CHECK(cout_tiles == nct, "morphfc: the pack must hold all %d output tiles in one block (cout_tiles = %d given)", nct, cout_tiles);
+  MorphK k;
+  memset(&k, 0, sizeof(k));
+  k.x = (const bf16*)x; k.mask = (const bf16*)relu_mask; k.out = (bf16*)out; k.wpack = (const char*)packed; k.bias = bias;
+  k.BT = BT; k.H = H; k.W = W; k.C = C; k.Cp = Cp; k.chunk = chunk; k.S = Cp / chunk; k.axis = axis;
+  const int len = axis == 0 ? H : W, lines = axis == 0 ? W : H;
+  k.gpl = cdiv(len, chunk);
+  k.ngroups = (long long)BT * lines * k.gpl;
+  const int G = 16 / chunk;
+  k.ntiles = cdiv64(k.ngroups, G);
+  k.relu = relu; k.in_scale = in_scale; k.out_scale = out_scale;
+  k.ss = morph_stage_stride(nct);
+  const int blkb = (16 * Cp * 2 + 15) & ~15;
+  const int lds = ((nk + 1) / 2) * k.ss + MF_WAVES * 2 * blkb;
+  VMG_CHECK(lds <= 160 * 1024, "morphfc: Cp = %d needs %d B of LDS (> 160 KiB): use the unfused path", Cp, lds);
+  hipStream_t st = (hipStream_t)stream;
+  const int ncu = vmg_cu_count(vmg_current_device());
+  long long nwg = cdiv64(k.ntiles, MF_WAVES);
+  if (nwg > ncu) nwg = ncu;  // one workgroup per CU (the LDS holds the weights): tiles are strided over the waves
+#define MF_CASE(NK_, NCT_)                                                                                          \
+  if (nk == NK_ && nct == NCT_) {                                                                                   \
+    auto fn = morph_linear_kernel<NK_, NCT_>;                                                                       \
+    static bool attr_set[VMG_MAX_DEVICES] = {};                                                                     \
+    const int dev = vmg_current_device();                                                                           \
+    if (!attr_set[dev]) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set[dev] = true;                                                                                         \
+    }                                                                                                               \
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(MF_WAVES * 64), lds, st, k);                                   \
+    VMG_LAUNCH_CHECK();                                                                                             \
+    return 0;                                                                                                       \
+  }
+  MF_CASE(5, 9)   // Cp = 144
+  MF_CASE(4, 7)   // Cp = 112
+  MF_CASE(1, 1)   // Cp = 16 (test configurations)
+  MF_CASE(1, 2)   // Cp = 32
+  MF_CASE(2, 4)   // Cp = 64
+#undef MF_CASE
+  vmg_set_error("morphfc: Cp = %d is not instantiated (144, 112, 64, 32, 16)", Cp);
+  return -1;
+}

@@ -505,6 +505,59 @@ def morph_untokens(t: torch.Tensor, axis: str, chunk: int, Cp: int, H: int, W: i
     return u.reshape(B, T, H, Wp, Cp)[..., 0:W, :C].contiguous()
 
 
+class _MorphLinear(torch.autograd.Function):
+    """One MorphFC branch: relu(tokens(x) W^T + b) / Cp back in pixel layout (models/function.py:763-772, 776-785) as ONE kernel with the
+    token reshuffle in the GEMM's addressing (vmg_morphfc_fwd).  Backward: the data gradient is the same kernel on (dy * relu'(y) / Cp)
+    with the transposed weight; only the weight gradient still needs the two token matrices (gathered here, summed by the batched
+    Linear weight-gradient GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, axis, chunk, Cp):
+        x = x.contiguous()
+        nct = (Cp + 15) // 16
+        y = K.morphfc_forward(x, axis, chunk, Cp, packed(weight, x.dtype, "fwd", [Cp], tiles=nct), bias, True, 1.0, 1.0 / Cp)
+        ctx.cfg = (axis, chunk, Cp)
+        ctx.has_bias = bias is not None
+        ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[1] and \
+            (bias is None or isinstance(bias, torch.nn.Parameter))
+        if ctx.defer:
+            ctx.gen = DEFERRED.note_use(weight, bias)
+            ctx.bias_ref = bias
+        ctx.save_for_backward(x, y, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight = ctx.saved_tensors
+        axis, chunk, Cp = ctx.cfg
+        dy = dy.contiguous()
+        nct = (Cp + 15) // 16
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.morphfc_forward(dy, axis, chunk, Cp, packed(weight, dy.dtype, "dgrad", None, 0, Cp, tiles=nct), None, False, 1.0 / Cp, 1.0, mask=y)
+        d_w = d_b = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            tok = morph_tokens(x, axis, chunk, Cp)                                                    # (B,T,G,chunk,Cp)
+            dpre = morph_tokens(K.act_backward(dy, y, hip.ACT_RELU, 0.0, 1.0 / Cp), axis, chunk, Cp)
+            M = tok.numel() // Cp
+            if ctx.defer:
+                DEFERRED.add(weight, ctx.bias_ref, [tok], [Cp], dpre, 1, 1, 1, M, gen=ctx.gen)
+            else:
+                d_w, d_b = _wgrad_now(weight, ctx.has_bias and ctx.needs_input_grad[2], [tok], [Cp], dpre, 1, 1, 1, M)
+        return dx, d_w, d_b, None, None, None
+
+
+def morph_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], axis: str, chunk: int, Cp: int) -> torch.Tensor:
+    """relu(Linear(tokens)) / Cp of one MorphFC branch on (B,T,H,W,C).  Fused kernel where it is instantiated; the general path gathers the
+    tokens, runs the Linear kernel and scatters back."""
+    B, T, H, W, C = x.shape
+    if K.morph_fused_ok(x, chunk, Cp):
+        return _MorphLinear.apply(x, weight, bias, axis, chunk, Cp)
+    t = morph_tokens(x, axis, chunk, Cp)
+    t = linear(t, weight, bias, act=hip.ACT_RELU, alpha=1.0 / Cp)
+    return morph_untokens(t, axis, chunk, Cp, H, W, C)
+
+
 class _ChannelAttention(torch.autograd.Function):
     """(r * sigmoid(W2 relu(W1 GAP(r) + b1) + b2) + x) * s on (N,H,W,C): CALayer + RCAB residual (models/function.py:555-558,
     581).  The two full-tensor passes (GAP reduction, scale+residual) are HIP kernels; the (N,C)-sized squeeze-excite MLP

@@ -369,6 +369,32 @@ def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rs
     return dx, dw, db
 
 
+MORPH_FUSED_CP = (144, 112, 64, 32, 16)
+
+
+def morph_fused_ok(x: torch.Tensor, chunk: int, Cp: int) -> bool:
+    """Shapes the fused MorphFC kernel (vmg_morphfc_fwd) covers: bf16, chunk dividing 16, Cp instantiated, C a multiple of 8."""
+    return x.dtype == torch.bfloat16 and 16 % chunk == 0 and Cp in MORPH_FUSED_CP and x.shape[-1] % 8 == 0 and Cp % chunk == 0
+
+
+def morphfc_forward(x: torch.Tensor, axis: str, chunk: int, Cp: int, pw: PackedConv, bias: Optional[torch.Tensor], relu: bool, in_scale: float,
+                    out_scale: float, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,T,H,W,C) contiguous bf16 -> the branch output in the same layout (vmg_morphfc_fwd); mask: the data-gradient form."""
+    hip.require_cuda(x, bias, mask)
+    B, T, H, W, C = x.shape
+    if not x.is_contiguous() or (mask is not None and (not mask.is_contiguous() or mask.shape != x.shape or mask.dtype != x.dtype)):
+        raise HipError("morphfc: contiguous x (and mask of the same shape) expected")
+    if pw.layout != "std" or pw.ks != 1 or pw.cout != Cp or pw.src_ch != [Cp] or pw.cout_tiles != (Cp + 15) // 16 or pw.dtype != torch.bfloat16:
+        raise HipError("morphfc: the pack must be a (Cp, Cp) 1x1 pack with all output tiles in one block")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cp or not bias.is_contiguous()):
+        raise HipError("morphfc: bias must be contiguous fp32 of length Cp")
+    out = torch.empty_like(x)
+    hip.check(hip.lib().vmg_morphfc_fwd(0 if axis == "h" else 1, chunk, x.data_ptr(), mask.data_ptr() if mask is not None else None, pw.buf.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), B * T, H, W, C, Cp, pw.cout_tiles, 1 if relu else 0,
+                                        in_scale, out_scale, hip.stream_ptr()), "vmg_morphfc_fwd")
+    return out
+
+
 def _win3d_geom(q, kv, table, heads, wt):
     B, D, H, W, C = q.shape
     if tuple(kv.shape) != (B, D, H, W, 2 * C) or kv.dtype != q.dtype or not q.is_contiguous() or not kv.is_contiguous():

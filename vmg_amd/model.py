@@ -228,12 +228,9 @@ class Enhanced_MorphFCs_decay(nn.Module):
         with torch.no_grad():  # T1: persistent, outside autograd, before the GEMM (function.py:766-768, 779-781)
             self.mlp_h[0].weight.mul_(self.gamma_h)
             self.mlp_w[0].weight.mul_(self.gamma_w)
-        th = FH.morph_tokens(x, "h", self.chunk_h, self.Ch)
-        th = lin(self.mlp_h[0], th, act=ACT_RELU, alpha=1.0 / self.Ch)
-        h = FH.morph_untokens(th, "h", self.chunk_h, self.Ch, H, W, C)
-        tw = FH.morph_tokens(x, "w", self.chunk_w, self.Cw)
-        tw = lin(self.mlp_w[0], tw, act=ACT_RELU, alpha=1.0 / self.Cw)
-        w = FH.morph_untokens(tw, "w", self.chunk_w, self.Cw, H, W, C)
+        # token reshuffle + Linear + ReLU + 1/Ch + inverse reshuffle: one kernel per branch where it is instantiated
+        h = FH.morph_linear(x, self.mlp_h[0].weight, self.mlp_h[0].bias, "h", self.chunk_h, self.Ch)
+        w = FH.morph_linear(x, self.mlp_w[0].weight, self.mlp_w[0].bias, "w", self.chunk_w, self.Cw)
         if isinstance(self.mlp_c, RCAB):
             c = self.mlp_c(x, out_scale=1.0 / C)
         else:
