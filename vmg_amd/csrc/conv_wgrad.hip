@@ -37,26 +37,34 @@ struct WgradK {
   float* db;
   float scale;
   int N, H, W, SEG;
+  int HB;  // row blocks per image (KS > 1: a K unit is UR rows x 32 pixels)
   long long M, U;
   int S;
   int vec_ok;  // 16-byte vector loads are legal for both operands
+  float* slab;  // non-null: every workgroup STORES its partial tile to slab[z][y][x][tile] (a reduce kernel sums the K splits in a fixed
+                // order) instead of adding it to dW with float atomics -- with few (co, ci) tiles and many K splits the atomics all hit the
+                // same few addresses and serialise (7x7: 131 us of a 140 us launch)
 };
 
-template <typename T, int KS, int CT, int IT>
+// UR: image rows per K unit (a unit = UR rows x 32 pixels).  The X tile with its halo is (UR + KS - 1) x (32 + KS - 1) pixels: for 7x7
+// one row per unit re-loads 7 rows of halo per 32 pixels; four rows per unit cut the X traffic per pixel 2.8-fold.
+template <typename T, int KS, int CT, int IT, int UR = 1>
 struct WgradCfg {
   static constexpr int ES = ElemTraits<T>::ES;
   static constexpr int KK = KS * KS;
-  static constexpr int XR = KS, XW = 32 + KS - 1;
+  static constexpr int XR = KS + UR - 1, XW = 32 + KS - 1;
+  static constexpr int UP = UR * 32;  // pixels per unit
   static constexpr int DYC = CT * 16, XC = IT * 16;
   static constexpr int DY_RS = DYC * ES + 16, X_RS = XC * ES + 16;  // LDS row (= pixel) strides in bytes
-  static constexpr int DY_BYTES = 32 * DY_RS, X_BYTES = XR * XW * X_RS;
+  static constexpr int DY_BYTES = UP * DY_RS, X_BYTES = XR * XW * X_RS;
   static constexpr int WAVE_BYTES = (DY_BYTES + X_BYTES + 15) & ~15;
   static constexpr int RED_RS = XC * KK + 2;  // floats per output-channel row of the reduction image
   static constexpr int RED_BYTES = (DYC * RED_RS + DYC) * 4;
-  static constexpr int LDS_BYTES = 4 * WAVE_BYTES + RED_BYTES;
+  // the reduction image takes over the waves' tiles once the main loop is done (behind a barrier)
+  static constexpr int LDS_BYTES = 4 * WAVE_BYTES > RED_BYTES ? 4 * WAVE_BYTES : RED_BYTES;
   static constexpr int VPL = 16 / ES;                        // elements per 16-byte vector
   static constexpr int DY_VPP = DYC / VPL, X_VPP = XC / VPL;  // vectors per pixel
-  static constexpr int DY_NV = (32 * DY_VPP + 63) / 64, X_NV = (XR * XW * X_VPP + 63) / 64;  // vectors per lane
+  static constexpr int DY_NV = (UP * DY_VPP + 63) / 64, X_NV = (XR * XW * X_VPP + 63) / 64;  // vectors per lane
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rs, int k0, int c0, int lane) {
@@ -71,15 +79,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rs, int k0, int 
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <typename T, int KS, int CT, int IT>
+template <typename T, int KS, int CT, int IT, int UR = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
-  using C = WgradCfg<T, KS, CT, IT>;
+  using C = WgradCfg<T, KS, CT, IT, UR>;
   constexpr int ES = C::ES, KK = C::KK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* dyt = smem + wave * C::WAVE_BYTES;
   char* xt = dyt + C::DY_BYTES;
-  float* red = reinterpret_cast<float*>(smem + 4 * C::WAVE_BYTES);
+  float* red = reinterpret_cast<float*>(smem);  // (valid behind the barrier that follows the main loop)
   float* redb = red + C::DYC * C::RED_RS;
 
   const int ob = blockIdx.x * C::DYC, ib = blockIdx.y * C::XC;  // channel offsets of this block
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     if (KS > 1) {
       const int seg = (int)(u % a.SEG);
       const long long r = u / a.SEG;
-      y = (int)(r % a.H);
-      n = (int)(r / a.H);
+      y = (int)(r % a.HB) * UR;
+      n = (int)(r / a.HB);
       x0 = seg * 32;
     } else {
       m0 = u * 32;
@@ -120,10 +128,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       const int p = idx / C::DY_VPP, v = idx - p * C::DY_VPP;
       uint4 val = make_uint4(0, 0, 0, 0);
       const int c = ob + v * C::VPL;
-      bool ok = (idx < 32 * C::DY_VPP);
+      bool ok = (idx < C::UP * C::DY_VPP);
       long long pix;
-      if (KS > 1) { ok = ok && (x0 + p < a.W); pix = ((long long)n * a.H + y) * a.W + x0 + p; }
-      else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
+      if (KS > 1) {
+        const int rr = p >> 5, col = p & 31;
+        ok = ok && (x0 + col < a.W) && (y + rr < a.H);
+        pix = ((long long)n * a.H + y + rr) * a.W + x0 + col;
+      } else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
       if (ok) {
         const char* src = dybase + (pix * a.dy_ps + c) * ES;
         if (a.vec_ok && c + C::VPL <= a.Cout) {
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     for (int k = 0; k < C::DY_NV; ++k) {
       const int idx = lane + 64 * k;
       const int p = idx / C::DY_VPP, v = idx - p * C::DY_VPP;
-      if (idx < 32 * C::DY_VPP) *reinterpret_cast<uint4*>(dyt + p * C::DY_RS + v * 16) = rdy[k];
+      if (idx < C::UP * C::DY_VPP) *reinterpret_cast<uint4*>(dyt + p * C::DY_RS + v * 16) = rdy[k];
     }
 #pragma unroll
     for (int k = 0; k < C::X_NV; ++k) {
@@ -191,37 +202,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     const long long un = u + 4;
     if (un < u_hi) load_unit(un);
     // wave-private tile: program order + the compiler's lgkmcnt waits are the only synchronisation needed
-    if constexpr (ES == 2) {
-      bf16x8 af[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, 0, ct * 16, lane);
+    for (int rr = 0; rr < UR; ++rr) {
+      if constexpr (ES == 2) {
+        bf16x8 af[CT];
 #pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const int ky = t / KS, kx = t % KS;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-          const bf16x8 bfg = tr_frag(xt + ky * C::XW * C::X_RS, C::X_RS, kx, it * 16, lane);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-            acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfg, acc[ct][t][it], 0, 0, 0);
-        }
-      }
-    } else {
-      const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float af[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const float*>(dyt + (4 * j + g) * C::DY_RS + (ct * 16 + l15) * 4);
+        for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, rr * 32, ct * 16, lane);
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
           const int ky = t / KS, kx = t % KS;
 #pragma unroll
           for (int it = 0; it < IT; ++it) {
-            const float bv = *reinterpret_cast<const float*>(xt + (ky * C::XW + 4 * j + g + kx) * C::X_RS + (it * 16 + l15) * 4);
+            const bf16x8 bfg = tr_frag(xt + (rr + ky) * C::XW * C::X_RS, C::X_RS, kx, it * 16, lane);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-              acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct], bv, acc[ct][t][it], 0, 0, 0);
+              acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfg, acc[ct][t][it], 0, 0, 0);
+          }
+        }
+      } else {
+        const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float af[CT];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const float*>(dyt + (rr * 32 + 4 * j + g) * C::DY_RS + (ct * 16 + l15) * 4);
+#pragma unroll
+          for (int t = 0; t < KK; ++t) {
+            const int ky = t / KS, kx = t % KS;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+              const float bv = *reinterpret_cast<const float*>(xt + ((rr + ky) * C::XW + 4 * j + g + kx) * C::X_RS + (it * 16 + l15) * 4);
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct)
+                acc[ct][t][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct], bv, acc[ct][t][it], 0, 0, 0);
+            }
           }
         }
       }
@@ -229,13 +243,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     if (do_bias && lane < C::DYC) {
       float s = 0.f;
 #pragma unroll 8
-      for (int p = 0; p < 32; ++p) s += to_f32(*reinterpret_cast<const T*>(dyt + p * C::DY_RS + lane * ES));
+      for (int p = 0; p < C::UP; ++p) s += to_f32(*reinterpret_cast<const T*>(dyt + p * C::DY_RS + lane * ES));
       bsum += s;
     }
     u = un;
   }
 
   // ---- cross-wave reduction in LDS, laid out [co][ci][tap] = OIHW order of this block
+  __syncthreads();  // every wave is done with its tiles: the reduction image reuses that memory
   for (int i = tid; i < C::DYC * C::RED_RS + C::DYC; i += 256) red[i] = 0.f;
   __syncthreads();
   {
@@ -253,6 +268,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   }
   __syncthreads();
   constexpr int ROW = C::XC * KK;
+  if (a.slab) {
+    constexpr int TILE = C::DYC * ROW + C::DYC;  // floats per workgroup: the tile, then the bias sums
+    float* dst = a.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * TILE;
+    for (int i = tid; i < C::DYC * ROW; i += 256) {
+      const int co = i / ROW, rem = i - co * ROW;
+      dst[i] = red[co * C::RED_RS + rem];
+    }
+    if (tid < C::DYC) dst[C::DYC * ROW + tid] = do_bias ? redb[tid] : 0.f;
+    return;
+  }
   for (int i = tid; i < C::DYC * ROW; i += 256) {
     const int co = i / ROW, rem = i - co * ROW;
     const int ci = rem / KK;
@@ -262,32 +287,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   if (do_bias && tid < C::DYC && ob + tid < a.Cout) atomicAdd(&a.db[a.o0 + ob + tid], redb[tid] * a.scale);
 }
 
-template <typename T, int KS, int CT, int IT>
+// sums the K splits of the slab form in a fixed order and adds the result to dW / db (one thread per element: no atomics)
+__global__ void wgrad_slab_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int DYC, int XC, int KK, int Cout, int Cin,
+                                         float* __restrict__ dW, int I_total, int o0, int i0, float* __restrict__ db, float scale) {
+  const int ROW = XC * KK, TILE = DYC * ROW + DYC;
+  const long long total = (long long)gx * gy * TILE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % TILE);
+    const int bxy = (int)(i / TILE);
+    const int bx = bxy % gx, by = bxy / gx;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slab[((size_t)z * gy * gx + bxy) * TILE + e];
+    if (e < DYC * ROW) {
+      const int co = e / ROW, rem = e - co * ROW, ci = rem / KK;
+      if (bx * DYC + co < Cout && by * XC + ci < Cin)
+        dW[((long long)(o0 + bx * DYC + co) * I_total + (i0 + by * XC)) * KK + rem] += s * scale;
+    } else if (db && by == 0) {
+      const int co = e - DYC * ROW;
+      if (bx * DYC + co < Cout) db[o0 + bx * DYC + co] += s * scale;
+    }
+  }
+}
+
+template <typename T, int KS, int CT, int IT, int UR = 1>
 int launch_wgrad(WgradK k, hipStream_t st) {
-  using C = WgradCfg<T, KS, CT, IT>;
+  using C = WgradCfg<T, KS, CT, IT, UR>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "wgrad LDS");
   const int gx = cdiv(k.Cout, C::DYC), gy = cdiv(k.Cin, C::XC);
   long long s = 1024 / ((long long)gx * gy);  // ~4 workgroups per CU in flight
   if (s > k.U / 32) s = k.U / 32;           // >= 8 K units per wave, or the float-atomic epilogue dominates
+  constexpr long long TILE = C::DYC * C::XC * C::KK + C::DYC;
+  if (k.slab) {  // the K splits must fit the workspace
+    const long long cap = k.M /* = workspace floats here, see wgrad_impl */ / ((long long)gx * gy * TILE);
+    if (s > cap) s = cap;
+  }
   if (s < 1) s = 1;
   if (s > 65535) s = 65535;
   k.S = (int)s;
-  auto fn = conv_wgrad_kernel<T, KS, CT, IT>;
+  auto fn = conv_wgrad_kernel<T, KS, CT, IT, UR>;
   static bool attr_set[VMG_MAX_DEVICES] = {};  // the attribute is per device
   const int dev = vmg_current_device();
   if (!attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
+  const long long ws_floats = k.slab ? k.M : 0;
+  k.M = (long long)k.N * k.H * k.W;
+  if (k.slab && (long long)gx * gy * k.S * TILE > ws_floats) k.slab = nullptr;  // (workspace too small even for one split: atomics)
   hipLaunchKernelGGL(fn, dim3(gx, gy, k.S), dim3(256), C::LDS_BYTES, st, k);
   VMG_LAUNCH_CHECK();
+  if (k.slab) {
+    const long long total = (long long)gx * gy * TILE;
+    const int rb = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)k.slab, k.S, gx, gy, C::DYC, C::XC, C::KK, k.Cout, k.Cin, k.dW,
+                       k.I_total, k.o0, k.i0, k.db, k.scale);
+    VMG_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 }  // namespace
 
 static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps,
-                      int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale, void* stream) {
+                      int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db, float scale, void* stream,
+                      float* ws = nullptr, int64_t ws_bytes = 0) {
   VMG_CHECK(ks == 1 || ks == 3 || ks == 7, "conv_wgrad: ks must be 1, 3 or 7");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_wgrad: bad dtype");
   VMG_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
@@ -308,10 +371,18 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
   k.dW = dW; k.I_total = I_total; k.o0 = o0; k.i0 = i0; k.db = db; k.scale = scale;
   k.N = N; k.H = H; k.W = W; k.M = (long long)N * H * W;
   k.SEG = cdiv(W, 32);
-  k.Upair = ks > 1 ? (long long)N * H * k.SEG : cdiv64(k.M, 32);
+  const int ur = 1;  // rows per K unit (must match the launch below; 2 and 4 rows spilled registers in the 49-tap instantiations)
+  k.HB = cdiv(H, ur);
+  k.Upair = ks > 1 ? (long long)N * k.HB * k.SEG : cdiv64(k.M, 32);
   k.U = k.Upair * npairs;
   hipStream_t st = (hipStream_t)stream;
-  if (ks == 7) return dtype == VMG_BF16 ? launch_wgrad<bf16, 7, 1, 1>(k, st) : launch_wgrad<float, 7, 1, 1>(k, st);  // 49 taps x one 16 x 16 tile per workgroup
+  if (ks == 7) {  // 49 taps x one 16 x 16 tile per workgroup; K splits reduced through the workspace when there is one
+    if (ws && ws_bytes >= (1 << 20)) {
+      k.slab = ws;
+      k.M = ws_bytes / 4;  // (launch_wgrad reads the workspace size from here and restores M)
+    }
+    return dtype == VMG_BF16 ? launch_wgrad<bf16, 7, 1, 1, 1>(k, st) : launch_wgrad<float, 7, 1, 1, 1>(k, st);
+  }
   if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
   return ks == 3 ? launch_wgrad<float, 3, 3, 1>(k, st) : launch_wgrad<float, 1, 3, 3>(k, st);
 }
@@ -778,7 +849,7 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   bool ok = ws && dtype == VMG_BF16 && ks == 3 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
             x_ps >= cin8 && dy_ps >= cout8;
   for (int p = 0; ok && p < npairs; ++p) ok = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
-  if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
+  if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream, (float*)ws, ws_bytes);
   VMG_CHECK(N > 0 && H > 0 && W > 0 && dW && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad arguments");
   Wgrad2K k;
   memset(&k, 0, sizeof(k));

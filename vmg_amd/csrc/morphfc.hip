@@ -45,10 +45,12 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
   const int rowb = a.Cp * 2;                 // bytes of a pixel row in the LDS blocks
   const int blkb = (16 * rowb + 15) & ~15;
   char* wl = smem;                                    // [NST][ss]
-  char* xblk = smem + NST * a.ss + wave * 2 * blkb;   // [16 pixels][Cp] bf16
+  float* lbias = reinterpret_cast<float*>(smem + NST * a.ss);  // [COB]
+  char* xblk = smem + NST * a.ss + COB * 4 + wave * 2 * blkb;  // [16 pixels][Cp] bf16
   char* oblk = xblk + blkb;
-  // weights -> LDS, once
+  // weights and bias -> LDS, once
   for (int i = tid * 16; i < NST * a.ss; i += MF_WAVES * 64 * 16) *reinterpret_cast<uint4*>(wl + i) = *reinterpret_cast<const uint4*>(a.wpack + i);
+  for (int i = tid; i < COB; i += MF_WAVES * 64) lbias[i] = (a.bias && i < a.Cp) ? a.bias[i] : 0.f;
   __syncthreads();
 
   const int tok = lane & 15, kq = lane >> 4;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (f0 + r < a.Cp) {
-          float v = acc[ct][r] + (a.bias ? a.bias[f0 + r] : 0.f);
+          float v = acc[ct][r] + lbias[f0 + r];
           if (a.relu) v = fmaxf(v, 0.f);
           *reinterpret_cast<bf16*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = (bf16)(v * a.out_scale);
         }
@@ -181,7 +183,7 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
   k.relu = relu; k.in_scale = in_scale; k.out_scale = out_scale;
   k.ss = morph_stage_stride(nct);
   const int blkb = (16 * Cp * 2 + 15) & ~15;
-  const int lds = ((nk + 1) / 2) * k.ss + MF_WAVES * 2 * blkb;
+  const int lds = ((nk + 1) / 2) * k.ss + nct * 16 * 4 + MF_WAVES * 2 * blkb;
   VMG_CHECK(lds <= 160 * 1024, "morphfc: Cp = %d needs %d B of LDS (> 160 KiB): use the unfused path", Cp, lds);
   hipStream_t st = (hipStream_t)stream;
   const int ncu = vmg_cu_count(vmg_current_device());

@@ -112,7 +112,10 @@ class SPyNet(nn.Module):
         for level in range(6):
             up = flow if level == 0 else FH.upsample2x_flow(flow, 2.0)
             warped = FH.grid_sample_flow(supps[level], up, "bilinear", "border")
-            res = self.basic_module[level]([refs[level][..., :3], warped[..., :3], up.to(dt)])
+            # one 8-channel operand [ref, warped, flow] (a 16-byte vector per pixel) instead of a virtual concat of 3 + 3 + 2 channels:
+            # the convolution and its weight gradient then move whole vectors
+            x8 = torch.cat([refs[level][..., :3], warped[..., :3], up.to(dt)], -1)
+            res = self.basic_module[level]([x8])
             flow = up + res.float()
         return flow
 
