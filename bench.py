@@ -24,22 +24,33 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, T, H, W = 4, 7, 64, 64
 FWD_GFLOP_PER_FRAME = 292.8  # Conv+Linear, measured on the reference (SURVEY section 6 / BASELINE.md section 2)
-K1_FLOPS_PER_PIXEL = 2.0 * 144 * 144 * 9  # the dominant kernel: conv3x3 144->144
-K1_PIXELS = 2 * B_PER_GPU * H * W          # ... over one frame of every clip for BOTH direction sweeps (run in lockstep)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# --workload: the default is the configuration BASELINE.json's metric is quoted on (configs[1]); the other two are the per-GPU
+# shards of configs[2] (full VMG-REDS, 8 clips over 8 GPUs = 1 clip per GPU) and configs[3] (sliding-window inference)
+WORKLOADS = {
+    "train": dict(cfg="few", batch=4, frames=7, size=64, ch=144,
+                  name="VMG-REDS-few_levels train step, per-GPU batch 4x7x3x64x64 -> 4x SR (BASELINE configs[1])"),
+    "train_full": dict(cfg="full", batch=1, frames=7, size=64, ch=112,
+                       name="VMG-REDS full config train step, per-GPU batch 1x7x3x64x64 -> 4x SR (BASELINE configs[2]: 8 clips over 8 GPUs)"),
+    "infer": dict(cfg="few", batch=1, frames=100, size=128, ch=144,
+                  name="VMG-REDS-few_levels sliding-window inference, 100 x 180x320 -> 720x1280, windows 50/25, tiles 128/20 (BASELINE configs[3])"),
+}
 
 
-def build_model(device):
+def build_model(device, wl=None):
     import vmg_amd
+    wl = wl or WORKLOADS["train"]
     # no MIOpen find mode (tools/train.py:111 of the reference asks for cudnn.benchmark): its search took 5 minutes of the driver's
     # bench run for the few ops left on PyTorch-ROCm; VMG_AUTOTUNE=1 turns it back on
     torch.backends.cudnn.benchmark = os.environ.get("VMG_AUTOTUNE") == "1"
-    from vmg_amd.data import REDS_FEW_LEVELS
+    from vmg_amd.data import REDS_FEW_LEVELS, REDS_FULL
     torch.manual_seed(0)
-    m = vmg_amd.VMG(num_frames=T, image_size=[64, 64], is_train=True, spynet_pretrained=None, compute_dtype=torch.bfloat16,
-                    **REDS_FEW_LEVELS)
+    infer = wl["frames"] > 50
+    m = vmg_amd.VMG(num_frames=50 if infer else wl["frames"], image_size=[wl["size"]] * 2, is_train=not infer, spynet_pretrained=None,
+                    compute_dtype=torch.bfloat16, **(REDS_FULL if wl["cfg"] == "full" else REDS_FEW_LEVELS))
     m.spynet = vmg_amd.SPyNet(None)  # the configs' SPyNet checkpoint is a download URL: random init, as stated in "data"
-    return m.to(device).train()
+    m = m.to(device)
+    return m.eval() if infer else m.train()
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -90,6 +101,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="train", help="train = BASELINE configs[1] (the metric's own "
+                    "configuration, the default); train_full / infer = the per-GPU shard of configs[2] / configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
@@ -131,21 +144,34 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from vmg_amd import hip
+    from vmg_amd import hip, infer
     from vmg_amd.data import synthetic_clip, synthetic_target
     from vmg_amd.train import TrainStep
 
-    model = build_model(device)
-    step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
-    lrs = synthetic_clip(B_PER_GPU, T, H, W, seed=1234 + rank, device=device)
-    hrs = synthetic_target(lrs, seed=4321 + rank)
+    wl = WORKLOADS[args.workload]
+    B, Tn, S = wl["batch"], wl["frames"], wl["size"]
+    model = build_model(device, wl)
+    if args.workload == "infer":
+        lrs = synthetic_clip(1, Tn, 180, 320, seed=7 + rank, device=device)
+
+        def step(_a, _b):
+            with torch.no_grad():
+                return infer.to_uint8(infer.test_clips(model, lrs, 50, 25, [128, 128], 20, 4))
+        hrs = None
+        k1_pixels = 2 * 1 * S * S
+    else:
+        step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
+        lrs = synthetic_clip(B, Tn, S, S, seed=1234 + rank, device=device)
+        hrs = synthetic_target(lrs, seed=4321 + rank)
+        k1_pixels = 2 * B * S * S  # one frame of every clip for BOTH direction sweeps (run in lockstep)
+    k1_flops = 2.0 * wl["ch"] * wl["ch"] * 9 * k1_pixels  # algorithmic FLOPs of one launch of the dominant kernel
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and not distributed
+    use_graph = args.graph and not distributed and args.workload == "train"
     mode = "eager"
     if use_graph:
         try:
@@ -168,7 +194,7 @@ def main():
     null_us = 0.0
     if not args.no_prof:
         null_us = float(lib.vmg_prof_null_interval_us(50, hip.stream_ptr()))  # event-pair interval of an empty kernel
-        hip.check(lib.vmg_prof_select_pixels(hip.ctx(), K1_PIXELS), "vmg_prof_select_pixels")
+        hip.check(lib.vmg_prof_select_pixels(hip.ctx(), k1_pixels), "vmg_prof_select_pixels")
         hip.check(lib.vmg_prof_begin(hip.ctx(), 1, 16, 4096), "vmg_prof_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -190,37 +216,43 @@ def main():
             # rocprofv3's kernel timestamps exclude.  null_kernel_interval_us (the same event pair around an empty one-wave
             # kernel) bounds that latency: rocprof's average lies between raw - null and raw.
             avg_s = raw_us * 1e-6
-            flops = K1_FLOPS_PER_PIXEL * K1_PIXELS  # algorithmic FLOPs of one launch
-            ach = flops / avg_s / 1e12
+            ach = k1_flops / avg_s / 1e12
             traffic = None  # HBM bytes per launch of this kernel from the PMC passes recorded under profiles/ (not measurable live)
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_g_k1_traffic.json")) as f:
-                    traffic = int(json.load(f)["traffic_bytes_per_launch"])
-            except Exception:
-                pass
-            roofline = {"bound": "mfma", "kernel": "conv3x3 144->144 bf16 on %d px (fwd + dgrad of the recurrent chains; both direction sweeps in one launch)" % K1_PIXELS,
+            if wl["ch"] == 144 and k1_pixels == 32768:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r02_b_k1_pmc.json")) as f:
+                        traffic = int(json.load(f)["traffic_bytes_per_launch"])
+                except Exception:
+                    pass
+            roofline = {"bound": "mfma", "kernel": "conv3x3 %d->%d bf16 on %d px (the weight-streaming kernel conv_ws_kernel: forward + input gradient of the "
+                                                   "recurrent residual chains; both direction sweeps in one launch)" % (wl["ch"], wl["ch"], k1_pixels),
                         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on tools/k1_traffic.py, profiles/r01_g_k1_traffic.json", "avg_launch_us": round(avg_s * 1e6, 2), "event_interval_us": round(raw_us, 2),
+                        "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on tools/k1_traffic.py, profiles/r02_b_k1_pmc.json",
+                        "avg_launch_us": round(avg_s * 1e6, 2), "event_interval_us": round(raw_us, 2),
                         "null_kernel_interval_us": round(null_us, 2), "launches_per_step": seen.value // max(1, args.steps),
                         "samples": n.value}
 
     if rank == 0:
         print("[bench] timed region done: %.3f s for %d steps" % (dt, args.steps), file=sys.stderr, flush=True)
-    frames = world * B_PER_GPU * T * args.steps
+    frames = world * B * Tn * args.steps
     value = frames / dt
+    train = args.workload != "infer"
     line = {
-        "metric": "LR-frames/s (train: forward+loss+backward+AdamW), VMG-REDS-few_levels 4x SR",
+        "metric": ("LR-frames/s (train: forward+loss+backward+AdamW), VMG-REDS%s 4x SR" % ("-few_levels" if wl["cfg"] == "few" else "")) if train
+        else "LR-frames/s (sliding-window inference incl. tile blending and uint8 conversion), VMG-REDS-few_levels 4x SR",
         "value": round(value, 3), "unit": "LR-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
-        "config": {"workload": "VMG-REDS-few_levels train step, per-GPU batch 4x7x3x64x64 -> 4x SR (BASELINE configs[1])",
-                   "global_batch": world * B_PER_GPU, "frames_per_clip": T, "lr_size": [H, W], "parallelism": f"dp{world}",
-                   "per_gpu_value": round(value / world, 3), "launch": mode,
-                   "model_tflops": round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2), "loss": float(loss)},
+        "config": {"workload": wl["name"], "global_batch": world * B, "frames_per_clip": Tn, "lr_size": [S, S] if train else [180, 320],
+                   "parallelism": f"dp{world}", "per_gpu_value": round(value / world, 3), "launch": mode},
         "roofline": roofline,
     }
+    if train:
+        line["config"]["loss"] = float(loss)
+    if args.workload == "train":
+        line["config"]["model_tflops"] = round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "train":
             line["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None

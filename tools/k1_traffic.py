@@ -1,5 +1,6 @@
-"""The dominant kernel alone (conv3x3 144->144 bf16, M = 32768, K-split with three 48-channel blocks, residual epilogue) for the
-PMC passes that give bench.py's roofline.traffic:   rocprofv3 --pmc FETCH_SIZE -- python3 tools/k1_traffic.py   (and WRITE_SIZE)."""
+"""The dominant kernel alone (conv3x3 144->144 bf16, M = 32768, weight-streaming kernel, residual epilogue) for the PMC passes behind
+bench.py's roofline.traffic and the MFMA-busy figure:
+    rocprofv3 --pmc FETCH_SIZE -- python3 tools/k1_traffic.py        (then WRITE_SIZE, then SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ..., each its own pass)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +13,8 @@ res = torch.randn(N, H, W, C, device="cuda").to(torch.bfloat16)
 w = torch.randn(C, C, 3, 3, device="cuda") * 0.03
 b = torch.randn(C, device="cuda")
 out = torch.empty_like(x)
-pw = K.pack_conv_weight(w, torch.bfloat16, cout_tiles=3)
+pw = K.pack_conv_weight_ws(w, cout_tiles=9)
 for _ in range(30):
-    K.conv_forward([x], pw, b, N, H, W, alpha=0.1, res=res, out=out, deep=2)
+    K.conv_forward([x], pw, b, N, H, W, alpha=0.1, res=res, out=out)
 torch.cuda.synchronize()
 print("done")

@@ -29,3 +29,12 @@ REDS_FEW_LEVELS = dict(  # network block of the reference's configs/VMG-REDS-few
     retention_decay=True, non_linear=True, gating=True, symm=True, symm_act="tanh", relu_scale=True, relu_scale_norm=False,
     ffn_type="ffn_cnn", mixer_type=["mlps", "mlps"], mixer_n=[None, None], r_scaling=0.1, chunk_ratios=["1/8", "1/4"],
     traj_mode="wins", twins=[2, 2], traj_scale=True, traj_refine=None, m_scaling=1.0, if_local_fuse=True, channel_mixer="rcab")
+
+REDS_FULL = dict(  # network block of the reference's configs/VMG-REDS.yml (4 encoder / 3 decoder levels); keys that file lacks keep VMG.__init__'s defaults
+    embed_dim=[112, 224, 224, 448, 224, 224, 112], depths=[4, 4, 2, 2, 2, 4, 4], num_heads=[4, 8, 8, 16, 8, 8, 4], mlp_ratio=6, n_groups=4,
+    window_sizes=[[2, 8, 8], [4, 8, 8], [6, 8, 8], [8, 8, 8], [6, 8, 8], [4, 8, 8], [2, 8, 8]], back_RBs=0, ltam=True,
+    traj_win=[16, None, None, None], traj_keyframes_n=[3, None, None, None], traj_heads=[4, None, None, None],
+    temporal_type=[False, None, None, None], temporal_empty=True, traj_res_n=[15, 0, 0, 0, 0, 0, 15], spatial_type=[False] * 4, mdsc=True,
+    if_concat=False, flow_smooth=True, smooth_region_range=4, retention_decay=True, non_linear=True, gating=True, symm=True, symm_act="tanh",
+    relu_scale=True, relu_scale_norm=False, ffn_type="ffn_cnn", mixer_type=["mlps"] * 4, mixer_n=[None] * 4, r_scaling=0.1,
+    chunk_ratios=["1/8", "1/4", "3/16", "1/8"], traj_mode="wins", twins=[2, 2], traj_scale=True, traj_refine=None, m_scaling=1.0)
