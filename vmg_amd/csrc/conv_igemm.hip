@@ -877,12 +877,14 @@ __global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int 
 // ================================================================================================ weight-streaming variant
 // conv_ws_kernel: bf16 3x3, ONE workgroup per 128-pixel tile (8 rows x 16 columns) and per block of NCT*16 output channels
 // (144 or 112: all of them for the convs of the recurrent chains), seven waves with fixed roles:
-//   * waves 4..6 are LOADERS: they copy the halo tile (10 x 18 pixels, all channels of a source block) and then stream the
-//     packed weights through a 3-slot LDS ring by LDS-DMA, one stage (= 3 k-steps = 3*NCT KiB; loader wave l copies k-step l)
-//     per barrier interval, one stage ahead of the one being consumed, with COUNTED s_waitcnt vmcnt;
-//   * waves 0..3 are CONSUMERS, one per SIMD: wave w accumulates pixel rows 2w, 2w+1 x all NCT channel tiles (2*NCT MFMAs per
-//     k-step from 2 activation + NCT weight fragments read from LDS, three static fragment sets, reads one k-step ahead,
-//     the last k-step of a stage multiplied AFTER the stage barrier so that the first reads of the next stage are covered).
+//   * waves 4..6 are LOADERS: they stream the packed weights through an LDS ring of R slots (4 when it fits, else 3) by LDS-DMA,
+//     one stage (= 3 k-steps = 3*NCT KiB; loader wave l copies k-step l) per barrier interval, ahead of the stage being consumed,
+//     with COUNTED s_waitcnt vmcnt; stage / piece order is rotated per workgroup;
+//   * waves 0..3 are CONSUMERS, one per SIMD: they first copy the halo tile (10 x 18 pixels, all channels of a source block; an
+//     inline-asm LDS-DMA the compiler does not see as one), then wave w accumulates pixel rows 2w, 2w+1 x all NCT channel tiles (2*NCT MFMAs
+//     per k-step from 2 activation + NCT weight fragments read from LDS, three static fragment sets, the reads of the next
+//     k-step interleaved one per MFMA gap);
+//   * the epilogue is done by ALL seven waves on (pixel, 8 channels) items out of an LDS patch placed in the ring.
 // Why: the K-split kernel above gives every 64-pixel x 48-channel workgroup its own copy of a third of the weights (124 KiB) and
 // of the halo (31 KiB) -- 238 MB through L2 -> CU per launch at M = 32 768, which is what bounds it (MFMA 23 % busy).  Here a CU
 // pulls the 373 KiB of weights ONCE for 128 pixels x 144 channels: 108 MB per launch, 256 workgroups = one per CU.
