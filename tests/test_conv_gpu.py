@@ -469,3 +469,27 @@ def test_conv7x7_fwd_dgrad_wgrad(dtype, shape):
     tol = 2e-4 if dtype == torch.float32 else 2e-3
     assert float((dW.cpu() - gw).abs().max()) <= tol * max(1.0, float(gw.abs().max()))
     assert float((db.cpu() - gb).abs().max()) <= tol * max(1.0, float(gb.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(6, 40, 70, 32, 64), (5, 33, 64, 64, 32), (48, 8, 8, 16, 2), (7, 21, 45, 8, 32)])
+def test_conv7x7_wgrad_slab_kernel(shape):
+    """The 7-wave 7x7 weight-gradient kernel with several K slabs, column segments and row blocks (W > 32, H not a multiple of
+    the 4-row unit), two (x, dy) pairs, a scale, and accumulation into an existing gradient."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co = shape
+    dt = torch.bfloat16
+    xs = [_q(R.seeded((N, H, W, Ci), 71 + i), dt) for i in range(2)]
+    dys = [_q(R.seeded((N, H, W, Co), 81 + i), dt) for i in range(2)]
+    w = torch.zeros(Co, Ci, 7, 7, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    loss = sum((O.conv_nhwc(x, w, b, 3) * dy).sum() for x, dy in zip(xs, dys))
+    gw, gb = torch.autograd.grad(loss, (w, b))
+    dW0, db0 = R.seeded((Co, Ci, 7, 7), 91), R.seeded((Co,), 92)
+    dW, db = dW0.cuda(), db0.cuda()
+    K.conv_wgrad_batched([x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys], dW, db, 7, N, H, W, scale=0.5)
+    wantW, wantb = dW0 + 0.5 * gw, db0 + 0.5 * gb
+    assert float((dW.cpu() - wantW).abs().max()) <= 2e-3 * max(1.0, float(wantW.abs().max()))
+    assert float((db.cpu() - wantb).abs().max()) <= 2e-3 * max(1.0, float(wantb.abs().max()))
+    dW2, db2 = dW0.cuda(), db0.cuda()
+    K.conv_wgrad_batched([x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys], dW2, db2, 7, N, H, W, scale=0.5)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)  # slabs are summed in a fixed order

@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int WG_MAX_PAIRS = 16;  // (x, dy) pairs summed by one launch (uses of a shared weight)
+__device__ __attribute__((aligned(256))) unsigned int g_zero_buf[64];  // 256 zero bytes: load / DMA source for out-of-image lanes
 
 struct WgradK {
   const char* x[WG_MAX_PAIRS];
@@ -40,7 +41,7 @@ struct WgradK {
   int HB;  // row blocks per image (KS > 1: a K unit is UR rows x 32 pixels)
   long long M, U;
   int S;
-  int vec_ok;  // 16-byte vector loads are legal for both operands
+  int vec_x, vec_dy;  // 16-byte vector loads are legal for the operand (pixel stride, channel count and base address are vector multiples)
   float* slab;  // non-null: every workgroup STORES its partial tile to slab[z][y][x][tile] (a reduce kernel sums the K splits in a fixed
                 // order) instead of adding it to dW with float atomics -- with few (co, ci) tiles and many K splits the atomics all hit the
                 // same few addresses and serialise (7x7: 131 us of a 140 us launch)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
   float bsum = 0.f;
 
   uint4 rdy[C::DY_NV], rx[C::X_NV];
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
 
   auto load_unit = [&](long long ug) {
     // which (x, dy) pair, then pixel coordinates of the unit inside it
@@ -122,39 +124,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
     } else {
       m0 = u * 32;
     }
-#pragma unroll
-    for (int k = 0; k < C::DY_NV; ++k) {
+    // Every load is UNCONDITIONAL: a lane outside the image (or past the channels) reads the zero buffer instead.  Loads behind a
+    // per-lane branch are each followed by an s_waitcnt vmcnt(0) -- ten serialised memory latencies per unit, which made even the
+    // 2 x 2-pixel SPyNet level cost 100 us.
+    auto dy_src = [&](int k, bool& ok, int& c) -> const char* {
       const int idx = lane + 64 * k;
       const int p = idx / C::DY_VPP, v = idx - p * C::DY_VPP;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      const int c = ob + v * C::VPL;
-      bool ok = (idx < C::UP * C::DY_VPP);
+      c = ob + v * C::VPL;
+      ok = (idx < C::UP * C::DY_VPP);
       long long pix;
       if (KS > 1) {
         const int rr = p >> 5, col = p & 31;
         ok = ok && (x0 + col < a.W) && (y + rr < a.H);
         pix = ((long long)n * a.H + y + rr) * a.W + x0 + col;
       } else { ok = ok && (m0 + p < a.M); pix = m0 + p; }
-      if (ok) {
-        const char* src = dybase + (pix * a.dy_ps + c) * ES;
-        if (a.vec_ok && c + C::VPL <= a.Cout) {
-          val = *reinterpret_cast<const uint4*>(src);
-        } else {
-          T tmp[C::VPL];
-#pragma unroll
-          for (int e = 0; e < C::VPL; ++e) tmp[e] = (c + e < a.Cout) ? reinterpret_cast<const T*>(src)[e] : from_f32<T>(0.f);
-          val = *reinterpret_cast<const uint4*>(tmp);
-        }
-      }
-      rdy[k] = val;
-    }
-#pragma unroll
-    for (int k = 0; k < C::X_NV; ++k) {
+      return dybase + (pix * a.dy_ps + c) * ES;
+    };
+    auto x_src = [&](int k, bool& ok, int& c) -> const char* {
       const int idx = lane + 64 * k;
       const int p = idx / C::X_VPP, v = idx - p * C::X_VPP;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      const int c = ib + v * C::VPL;
-      bool ok = (idx < C::XR * C::XW * C::X_VPP);
+      c = ib + v * C::VPL;
+      ok = (idx < C::XR * C::XW * C::X_VPP);
       long long pix;
       if (KS > 1) {
         const int r = p / C::XW, col = p - r * C::XW;
@@ -165,18 +155,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
         ok = ok && (m0 + p < a.M);
         pix = m0 + p;
       }
-      if (ok) {
-        const char* src = xbase + (pix * a.x_ps + c) * ES;
-        if (a.vec_ok && c + C::VPL <= a.Cin) {
-          val = *reinterpret_cast<const uint4*>(src);
-        } else {
-          T tmp[C::VPL];
+      return xbase + (pix * a.x_ps + c) * ES;
+    };
+    if (a.vec_dy) {
 #pragma unroll
-          for (int e = 0; e < C::VPL; ++e) tmp[e] = (c + e < a.Cin) ? reinterpret_cast<const T*>(src)[e] : from_f32<T>(0.f);
-          val = *reinterpret_cast<const uint4*>(tmp);
-        }
+      for (int k = 0; k < C::DY_NV; ++k) {
+        bool ok; int c;
+        const char* src = dy_src(k, ok, c);
+        rdy[k] = *reinterpret_cast<const uint4*>((ok && c + C::VPL <= a.Cout) ? src : zsrc);
       }
-      rx[k] = val;
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::DY_NV; ++k) {
+        bool ok; int c;
+        const char* src = dy_src(k, ok, c);
+        T tmp[C::VPL];
+#pragma unroll
+        for (int e = 0; e < C::VPL; ++e) tmp[e] = *reinterpret_cast<const T*>((ok && c + e < a.Cout) ? src + e * ES : zsrc);
+        rdy[k] = *reinterpret_cast<const uint4*>(tmp);
+      }
+    }
+    if (a.vec_x) {
+#pragma unroll
+      for (int k = 0; k < C::X_NV; ++k) {
+        bool ok; int c;
+        const char* src = x_src(k, ok, c);
+        rx[k] = *reinterpret_cast<const uint4*>((ok && c + C::VPL <= a.Cin) ? src : zsrc);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::X_NV; ++k) {
+        bool ok; int c;
+        const char* src = x_src(k, ok, c);
+        T tmp[C::VPL];
+#pragma unroll
+        for (int e = 0; e < C::VPL; ++e) tmp[e] = *reinterpret_cast<const T*>((ok && c + e < a.Cin) ? src + e * ES : zsrc);
+        rx[k] = *reinterpret_cast<const uint4*>(tmp);
+      }
     }
   };
 
@@ -359,12 +374,14 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
   const int es = dtype == VMG_BF16 ? 2 : 4, vpl = 16 / es;
   WgradK k;
   memset(&k, 0, sizeof(k));
-  k.vec_ok = (x_ps % vpl == 0) && (dy_ps % vpl == 0);
+  k.vec_x = (x_ps % vpl == 0) && (Cin % vpl == 0);
+  k.vec_dy = (dy_ps % vpl == 0) && (Cout % vpl == 0);
   for (int p = 0; p < npairs; ++p) {
     VMG_CHECK(x[p] && dy[p], "conv_wgrad: null pointer in pair %d", p);
     k.x[p] = (const char*)x[p];
     k.dy[p] = (const char*)dy[p];
-    k.vec_ok = k.vec_ok && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
+    k.vec_x = k.vec_x && ((uintptr_t)x[p] % 16 == 0);
+    k.vec_dy = k.vec_dy && ((uintptr_t)dy[p] % 16 == 0);
   }
   k.npairs = npairs;
   k.x_ps = x_ps; k.Cin = Cin; k.dy_ps = dy_ps; k.Cout = Cout;
@@ -414,7 +431,6 @@ extern "C" int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void*
 // =====================================================================================================
 namespace {
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_buf[64];  // 256 zero bytes: DMA source for out-of-image lanes
 
 struct Wgrad2K {
   const char* x[WG_MAX_PAIRS];
@@ -808,6 +824,218 @@ __global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* 
   }
 }
 
+// =====================================================================================================
+// 7x7 (SPyNet's ConvModules, reference models/vmg.py:126-173), bf16: dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p + (ky-3, kx-3)][ci].
+// Workgroup = SEVEN waves, wave ky owns tap row ky: CT output-channel tiles x 7 kx = 7*CT accumulator tiles of one 16-channel ci
+// block (grid.x = ci blocks, grid.y = K slabs).  A K unit = W7_R image rows x 32 pixels: the dY tile (R x 32 pixels x CT*16
+// channels) and the X tile with its 3-pixel halo ((R + 6) x 38 pixels x 16 channels) are fetched by all 448 threads with
+// UNCONDITIONAL 16-byte loads (lanes outside the image / past the channels read a zero buffer) one unit ahead into registers,
+// written to one of two LDS buffers, one barrier per unit.  Per image row a wave reads CT dY fragments and 7 X fragments (the
+// same staged row serves all kx: the fragment's first pixel is kx) transposed with ds_read_b64_tr_b16 for 7*CT MFMAs.  Every
+// (co, ci, tap) lives in exactly one wave: no reduction inside the workgroup; slab partials in the accumulators' native layout
+// (coalesced float4 stores) and a second kernel sums the slabs in a fixed order (deterministic) into dW / db.  The bias
+// gradient is one more MFMA per co tile against a ones vector on wave 0 of ci block 0.
+constexpr int W7_R = 4, W7_THREADS = 448, W7_XW = 38, W7_XR = W7_R + 6;
+constexpr int W7_X_RS = 48;                          // LDS pixel stride of the X tile: 16 channels + 16 bytes (conflict-free transposed reads)
+constexpr int W7_XVEC = W7_XR * W7_XW * 2;           // 760 16-byte vectors
+constexpr int W7_NX = (W7_XVEC + W7_THREADS - 1) / W7_THREADS;
+constexpr int W7_X_BYTES = (W7_NX * W7_THREADS / 2) * W7_X_RS;  // room for every thread's NX vectors: the staging stores are unconditional
+template <int CT>
+struct W7Cfg {
+  static constexpr int DY_RS = CT * 32 + 16, DYVEC = W7_R * 32 * CT * 2;
+  static constexpr int NX = W7_NX, NDY = (DYVEC + W7_THREADS - 1) / W7_THREADS;
+  static constexpr int DY_BYTES = ((NDY * W7_THREADS + CT * 2 - 1) / (CT * 2)) * DY_RS;  // (same: room for the padding vectors)
+  static constexpr int BUF = (W7_X_BYTES + DY_BYTES + 15) & ~15;
+  static constexpr int WG_FLOATS = (49 * CT + CT) * 256;  // tiles [ky][ct][kx], then the CT bias tiles
+};
+
+struct Wgrad7K {
+  const char* x[WG_MAX_PAIRS];
+  const char* dy[WG_MAX_PAIRS];
+  int npairs;
+  int Upair, U;       // K units per pair / in total
+  long long x_ps, dy_ps;
+  int Cin, Cout;      // true channel counts
+  int vec_dy;         // dY can be read as 16-byte vectors (else element by element: the 2-channel flow head)
+  float* slab;        // [S][ci blocks][WG_FLOATS]
+  int N, H, W, SEG, HB, S;
+  int has_bias;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int CT>
+__global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a) {
+  using C = W7Cfg<CT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ib = blockIdx.x * 16;
+  const int u_lo = (int)((long long)a.U * blockIdx.y / a.S), u_hi = (int)((long long)a.U * (blockIdx.y + 1) / a.S);
+  const bool do_bias = a.has_bias && blockIdx.x == 0 && ky == 0;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
+
+  f32x4 acc[CT][7], accb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    accb[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) acc[ct][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const __bf16 one = (__bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  u32x4 rx[C::NX], rdy[C::NDY];  // (a native vector type: the HIP uint4 struct is copied with memcpy and stays in scratch)
+  auto fetch = [&](int ug) __attribute__((always_inline)) {
+    const int pair = ug / a.Upair;
+    int u = ug - pair * a.Upair;
+    const int seg = u % a.SEG;
+    u /= a.SEG;
+    const int hb = u % a.HB, n = u / a.HB;
+    const int y0 = hb * W7_R, x0 = seg * 32;
+    const char* xb = a.x[pair];
+    const char* db_ = a.dy[pair];
+#pragma unroll
+    for (int k = 0; k < C::NX; ++k) {
+      const int idx = tid + k * W7_THREADS;
+      const int pp = idx >> 1, v = idx & 1;
+      const int r = pp / W7_XW, col = pp - r * W7_XW;
+      const int yy = y0 + r - 3, xx = x0 + col - 3, c = ib + v * 8;
+      const bool ok = idx < W7_XVEC && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c + 8 <= a.Cin;
+      const long long off = ((((long long)n * a.H + yy) * a.W + xx) * a.x_ps + c) * 2;
+      rx[k] = *reinterpret_cast<const u32x4*>(ok ? xb + off : zsrc);
+    }
+    if (a.vec_dy) {
+#pragma unroll
+      for (int k = 0; k < C::NDY; ++k) {
+        const int idx = tid + k * W7_THREADS;
+        const int pp = idx / (CT * 2), v = idx - pp * (CT * 2);
+        const int rr = pp >> 5, col = pp & 31;
+        const bool ok = idx < C::DYVEC && y0 + rr < a.H && x0 + col < a.W && v * 8 + 8 <= a.Cout;
+        const long long off = ((((long long)n * a.H + y0 + rr) * a.W + x0 + col) * a.dy_ps + v * 8) * 2;
+        rdy[k] = *reinterpret_cast<const u32x4*>(ok ? db_ + off : zsrc);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::NDY; ++k) {
+        const int idx = tid + k * W7_THREADS;
+        const int pp = idx / (CT * 2), v = idx - pp * (CT * 2);
+        const int rr = pp >> 5, col = pp & 31;
+        const bool ok = idx < C::DYVEC && y0 + rr < a.H && x0 + col < a.W;
+        const long long off = ((((long long)n * a.H + y0 + rr) * a.W + x0 + col) * a.dy_ps + v * 8) * 2;
+        unsigned short tmp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmp[e] = *reinterpret_cast<const unsigned short*>((ok && v * 8 + e < a.Cout) ? db_ + off + 2 * e : zsrc);
+        rdy[k] = u32x4{tmp[0] | (unsigned)tmp[1] << 16, tmp[2] | (unsigned)tmp[3] << 16, tmp[4] | (unsigned)tmp[5] << 16, tmp[6] | (unsigned)tmp[7] << 16};
+      }
+    }
+  };
+  auto stage = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < C::NX; ++k) {
+      const int idx = tid + k * W7_THREADS;
+      *reinterpret_cast<u32x4*>(buf + (idx >> 1) * W7_X_RS + (idx & 1) * 16) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < C::NDY; ++k) {
+      const int idx = tid + k * W7_THREADS;
+      const int pp = idx / (CT * 2), v = idx - pp * (CT * 2);
+      *reinterpret_cast<u32x4*>(buf + W7_X_BYTES + pp * C::DY_RS + v * 16) = rdy[k];
+    }
+  };
+
+  int which = 0;
+  if (u_lo < u_hi) fetch(u_lo);
+  for (int u = u_lo; u < u_hi; ++u) {
+    char* buf = smem + which * C::BUF;
+    stage(buf);
+    __syncthreads();  // the unit is complete in `buf`; every wave has finished the unit before the previous one (the other buffer is free again after the NEXT barrier)
+    if (u + 1 < u_hi) fetch(u + 1);
+    const char* xt = buf;
+    const char* dyt = buf + W7_X_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < W7_R; ++rr) {
+      bf16x8 af[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, rr * 32, ct * 16, lane);
+      const char* xrow = xt + (rr + ky) * (W7_XW * W7_X_RS);
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const bf16x8 bfg = tr_frag(xrow, W7_X_RS, kx, 0, lane);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfg, acc[ct][kx], 0, 0, 0);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], ones, accb[ct], 0, 0, 0);
+      }
+    }
+    which ^= 1;
+  }
+
+  float* sl = a.slab + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * C::WG_FLOATS;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx)
+      *reinterpret_cast<f32x4*>(sl + (((ky * CT + ct) * 7 + kx) * 64 + lane) * 4) = acc[ct][kx];
+  if (ky == 0) {  // (written by every ci block so that the reduce kernel never reads uninitialised memory)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<f32x4*>(sl + ((49 * CT + ct) * 64 + lane) * 4) = accb[ct];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad7_reduce_kernel(const float* __restrict__ slab, int S, int gx, int CT, int Cin, int Cout,
+                                                                 float* __restrict__ dW, int I_total, int o0, int i0,
+                                                                 float* __restrict__ db, float scale) {
+  __shared__ float red[256];
+  const int wgf = (49 * CT + CT) * 256;
+  const long long per_s = (long long)gx * wgf;
+  for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
+    const long long i = e0 + (threadIdx.x & 63);
+    const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
+    if (threadIdx.x >= 64) continue;
+    const int ciblk = (int)(i / wgf);
+    const int e = (int)(i - (long long)ciblk * wgf);
+    const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+    const int g = lane >> 4, l15 = lane & 15;
+    if (tile < 49 * CT) {
+      const int kx = tile % 7, ct = (tile / 7) % CT, ky = tile / (7 * CT);
+      const int co = ct * 16 + 4 * g + r, ci = ciblk * 16 + l15;
+      if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 49 + ky * 7 + kx] += sum * scale;
+    } else if (db && ciblk == 0 && l15 == 0) {
+      const int co = (tile - 49 * CT) * 16 + 4 * g + r;
+      if (co < Cout) db[o0 + co] += sum * scale;
+    }
+  }
+}
+
+template <int CT>
+int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, float scale, int64_t ws_bytes, hipStream_t st) {
+  using C = W7Cfg<CT>;
+  const int gx = cdiv(k.Cin, 16);
+  long long S = 512 / gx;            // ~two rounds of workgroups over the 256 CUs
+  if (S > k.U / 2) S = k.U / 2;      // >= 2 units per workgroup
+  const long long cap = ws_bytes / ((long long)gx * C::WG_FLOATS * 4);
+  if (S > cap) S = cap;
+  if (S < 1) S = 1;
+  if (cap < 1) return 1;  // (workspace too small: the caller falls back)
+  k.S = (int)S;
+  auto fn = conv_wgrad7_kernel<CT>;
+  static bool attr7[VMG_MAX_DEVICES] = {};  // per instantiation and device
+  const int dev = vmg_current_device();
+  if (!attr7[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::BUF);
+    attr7[dev] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(gx, (unsigned)S), dim3(W7_THREADS), 2 * C::BUF, st, k);
+  VMG_LAUNCH_CHECK();
+  const long long per_s = (long long)gx * C::WG_FLOATS;
+  const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
+  hipLaunchKernelGGL(conv_wgrad7_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)k.slab, (int)S, gx, CT, k.Cin, k.Cout, dW, I_total, o0, i0, db, scale);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W3_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~94 MB)
@@ -842,6 +1070,30 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
       return 0;
     }
   }
+  if (ws && dtype == VMG_BF16 && ks == 7 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && (x_ps % 8 == 0) && (Cin % 8 == 0) && x_ps >= Cin &&
+      dy_ps >= Cout && Cout <= 64 && N > 0 && H > 0 && W > 0 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0 &&
+      (long long)npairs * N * cdiv(H, W7_R) * cdiv(W, 32) < (1LL << 30)) {
+    bool al = true, vdy = (dy_ps % 8 == 0) && (Cout % 8 == 0);
+    for (int p = 0; al && p < npairs; ++p) {
+      al = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 2 == 0);
+      vdy = vdy && ((uintptr_t)dy[p] % 16 == 0);
+    }
+    if (al) {
+      Wgrad7K k;
+      memset(&k, 0, sizeof(k));
+      for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
+      k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.vec_dy = vdy ? 1 : 0; k.slab = (float*)ws;
+      k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32); k.HB = cdiv(H, W7_R);
+      k.Upair = N * k.HB * k.SEG; k.U = k.Upair * npairs;
+      k.has_bias = db != nullptr;
+      hipStream_t st = (hipStream_t)stream;
+      const int ct = cdiv(Cout, 16);
+      const int rc = ct == 1 ? launch_wgrad7<1>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
+                   : ct == 2 ? launch_wgrad7<2>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
+                             : launch_wgrad7<4>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st);
+      if (rc <= 0) return rc;
+    }
+  }
   // the large-tile path needs bf16, 3x3, 16-byte aligned 8-channel vectors; anything else takes the v1 kernel
   // (a channel count that is not a multiple of 8 is fine when the pixel stride has room for the whole last vector -- the
   // zero-padded input of the 3-channel stem conv, a slice of a wider tensor: the extra channels are computed and dropped)
@@ -866,10 +1118,11 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
   hipStream_t st = (hipStream_t)stream;
   k.S = (int)S; k.slab = (float*)ws;
-  static bool attr3 = false;
-  if (!attr3) {
+  static bool attr3[VMG_MAX_DEVICES] = {};  // the attribute is per device
+  const int dev3 = vmg_current_device();
+  if (!attr3[dev3]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr3 = true;
+    attr3[dev3] = true;
   }
   hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 6 * W3_BUF, st, k);
   VMG_LAUNCH_CHECK();
