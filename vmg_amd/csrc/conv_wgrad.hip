@@ -24,6 +24,22 @@ namespace {
 constexpr int WG_MAX_PAIRS = 16;  // (x, dy) pairs summed by one launch (uses of a shared weight)
 __device__ __attribute__((aligned(256))) unsigned int g_zero_buf[64];  // 256 zero bytes: load / DMA source for out-of-image lanes
 
+// The gx * gy workgroups of one K slab stream the SAME dY / X lines.  The hardware hands workgroup L of a 1-D grid to XCD L % 8 (each XCD
+// has its own L2), so the logical index is permuted: the blocks of a slab are consecutive on ONE XCD, run at the same time and
+// share the lines through that L2 instead of fetching them gx * gy times from HBM.
+struct SlabBlock { int x, y, z; };
+__device__ __forceinline__ SlabBlock xcd_slab_block(int gx, int gy, int S) {
+  const int T = gx * gy * S, L = blockIdx.x;
+  const int xcd = L & 7, j = L >> 3, rem = T & 7;
+  const int w = xcd * (T >> 3) + (xcd < rem ? xcd : rem) + j;
+  SlabBlock b;
+  b.x = w % gx;
+  const int t = w / gx;
+  b.y = t % gy;
+  b.z = t / gy;
+  return b;
+}
+
 struct WgradK {
   const char* x[WG_MAX_PAIRS];
   const char* dy[WG_MAX_PAIRS];
@@ -442,6 +458,7 @@ struct Wgrad2K {
   float* slab;       // [S][ciblk][coblk][8 waves][36 tiles][64][4]
   int N, H, W, SEG, S;
   int has_bias;
+  int gx, gy;        // co / ci blocks (the grid is 1-D: gx * gy * S workgroups, see xcd_slab_block)
 };
 
 constexpr int W2_WAVES = 9, W2_THREADS = 576;  // the 1x1 kernel's workgroup
@@ -501,8 +518,9 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave >> 2, q = wave & 3;
-  const int ob = blockIdx.x * W2_DYC, ib = blockIdx.y * W2_XC;
-  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S);
+  const int ob = blk.x * W2_DYC, ib = blk.y * W2_XC;
+  const long long u_lo = a.U * blk.z / a.S, u_hi = a.U * (blk.z + 1) / a.S;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
 
   f32x4 acc[5][7];
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
       for (int c = 0; c < 5; ++c) acc[c][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[jj], acc[c][jj], 0, 0, 0);
       bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
     }
-    if (a.has_bias && q == 0 && blockIdx.y == 0) {
+    if (a.has_bias && q == 0 && blk.y == 0) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
@@ -645,13 +663,13 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
-  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W3_WAVES + wave) * (W3_TILES * 256);
+  float* sl = a.slab + ((((long long)blk.z * a.gy + blk.y) * a.gx + blk.x) * W3_WAVES + wave) * (W3_TILES * 256);
 #pragma unroll
   for (int c = 0; c < 5; ++c)
 #pragma unroll
     for (int j = 0; j < 7; ++j) *reinterpret_cast<f32x4*>(sl + ((c * 7 + j) * 64 + lane) * 4) = acc[c][j];
   // bias tile: rows 4g..4g+3 of co tile c live in every column of D; column l15 < 5 of the slot carries co tile l15
-  if (a.has_bias && q == 0 && blockIdx.y == 0) {
+  if (a.has_bias && q == 0 && blk.y == 0) {
     f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
     if (li < 5) pack = li == 0 ? accb[0] : (li == 1 ? accb[1] : (li == 2 ? accb[2] : (li == 3 ? accb[3] : accb[4])));
     *reinterpret_cast<f32x4*>(sl + (35 * 64 + lane) * 4) = pack;
@@ -713,6 +731,7 @@ struct Lgrad2K {
   int Cin, Cout;
   float* slab;  // [S][ciblk][coblk][9 waves][10 tiles][64][4]
   int S, has_bias;
+  int gx, gy;   // co / ci blocks (1-D grid of gx * gy * S workgroups, see xcd_slab_block)
 };
 constexpr int L2_TILE_BYTES = 32 * 144 * 2;  // 9216
 constexpr int L2_BUF = 2 * L2_TILE_BYTES;    // dY tile + X tile
@@ -723,8 +742,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = wave / 3, it = wave - cg * 3;
-  const int ob = blockIdx.x * 144, ib = blockIdx.y * 144;
-  const long long u_lo = a.U * blockIdx.z / a.S, u_hi = a.U * (blockIdx.z + 1) / a.S;
+  const SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S);
+  const int ob = blk.x * 144, ib = blk.y * 144;
+  const long long u_lo = a.U * blk.z / a.S, u_hi = a.U * (blk.z + 1) / a.S;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
 
   f32x4 acc[3][3];
@@ -772,7 +792,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[j], acc[c][j], 0, 0, 0);
-    if (a.has_bias && it == 0 && blockIdx.y == 0) {
+    if (a.has_bias && it == 0 && blk.y == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
@@ -780,12 +800,12 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     buf = buf == 2 ? 0 : buf + 1;
   }
-  float* sl = a.slab + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W2_WAVES + wave) * (L2_TILES * 256);
+  float* sl = a.slab + ((((long long)blk.z * a.gy + blk.y) * a.gx + blk.x) * W2_WAVES + wave) * (L2_TILES * 256);
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(sl + ((c * 3 + j) * 64 + lane) * 4) = acc[c][j];
-  if (a.has_bias && it == 0 && blockIdx.y == 0) {
+  if (a.has_bias && it == 0 && blk.y == 0) {
     f32x4 pack = f32x4{0.f, 0.f, 0.f, 0.f};
     const int l15 = lane & 15;
     if (l15 < 3) pack = l15 == 0 ? accb[0] : (l15 == 1 ? accb[1] : accb[2]);
@@ -860,6 +880,7 @@ struct Wgrad7K {
   float* slab;        // [S][ci blocks][WG_FLOATS]
   int N, H, W, SEG, HB, S;
   int has_bias;
+  int gx;             // ci blocks (1-D grid of gx * S workgroups, see xcd_slab_block)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -869,9 +890,10 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ib = blockIdx.x * 16;
-  const int u_lo = (int)((long long)a.U * blockIdx.y / a.S), u_hi = (int)((long long)a.U * (blockIdx.y + 1) / a.S);
-  const bool do_bias = a.has_bias && blockIdx.x == 0 && ky == 0;
+  const SlabBlock blk = xcd_slab_block(a.gx, 1, a.S);
+  const int ib = blk.x * 16;
+  const int u_lo = (int)((long long)a.U * blk.z / a.S), u_hi = (int)((long long)a.U * (blk.z + 1) / a.S);
+  const bool do_bias = a.has_bias && blk.x == 0 && ky == 0;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
 
   f32x4 acc[CT][7], accb[CT];
@@ -972,7 +994,7 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
     which ^= 1;
   }
 
-  float* sl = a.slab + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * C::WG_FLOATS;
+  float* sl = a.slab + ((long long)blk.z * a.gx + blk.x) * C::WG_FLOATS;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -1019,7 +1041,7 @@ int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, 
   if (S > cap) S = cap;
   if (S < 1) S = 1;
   if (cap < 1) return 1;  // (workspace too small: the caller falls back)
-  k.S = (int)S;
+  k.S = (int)S; k.gx = gx;
   auto fn = conv_wgrad7_kernel<CT>;
   static bool attr7[VMG_MAX_DEVICES] = {};  // per instantiation and device
   const int dev = vmg_current_device();
@@ -1027,7 +1049,7 @@ int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::BUF);
     attr7[dev] = true;
   }
-  hipLaunchKernelGGL(fn, dim3(gx, (unsigned)S), dim3(W7_THREADS), 2 * C::BUF, st, k);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(gx * S)), dim3(W7_THREADS), 2 * C::BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per_s = (long long)gx * C::WG_FLOATS;
   const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
@@ -1060,8 +1082,9 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
       for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
       k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.S = (int)S; k.slab = (float*)ws;
       k.has_bias = db != nullptr;
+      k.gx = gx; k.gy = gy;
       hipStream_t st = (hipStream_t)stream;
-      hipLaunchKernelGGL(linear_wgrad2_kernel, dim3(gx, gy, (unsigned)S), dim3(W2_THREADS), 3 * L2_BUF, st, k);
+      hipLaunchKernelGGL(linear_wgrad2_kernel, dim3((unsigned)(gx * gy * S)), dim3(W2_THREADS), 3 * L2_BUF, st, k);
       VMG_LAUNCH_CHECK();
       const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
       const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
@@ -1117,14 +1140,14 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   const long long need = S * gx * gy * W3_WG_FLOATS * 4;
   if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
   hipStream_t st = (hipStream_t)stream;
-  k.S = (int)S; k.slab = (float*)ws;
+  k.S = (int)S; k.slab = (float*)ws; k.gx = gx; k.gy = gy;
   static bool attr3[VMG_MAX_DEVICES] = {};  // the attribute is per device
   const int dev3 = vmg_current_device();
   if (!attr3[dev3]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr3[dev3] = true;
   }
-  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(gx, gy, (unsigned)S), dim3(W3_THREADS), 6 * W3_BUF, st, k);
+  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)(gx * gy * S)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
   const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
