@@ -129,3 +129,32 @@ def test_fused_morphfc_branch_fwd_bwd(cfg, axis):
     assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= 3e-2 * max(1e-6, float(wg[0].abs().max()))
     assert float((wd.grad.cpu() - wg[1]).abs().max()) <= 3e-2 * max(1e-6, float(wg[1].abs().max()))
     assert float((bd.grad.cpu() - wg[2]).abs().max()) <= 3e-2 * max(1e-6, float(wg[2].abs().max()))
+
+
+@pytest.mark.parametrize("case", [(28, 144, 18, 144, "relu", 0), (4, 144, 36, 432, "gelu", 1), (7, 448, 56, 448, "relu", 0), (1, 112, 28, 336, "gelu", 1),
+                                  (70, 32, 4, 96, "gelu", 1)])
+def test_se_mlp_fwd_bwd_matches_torch(case):
+    """The one-launch squeeze-excite MLPs (CALayer.conv_du: ReLU + sigmoid; MorphFC reweight: GELU + softmax over the three branches)
+    against torch autograd on the same fp32 values: outputs, input gradient (with the 1/R scale) and all four parameter gradients."""
+    import torch.nn.functional as F
+    from oracle import recipe as R
+    from vmg_amd import hip, kernels as K
+    G, C, Hd, Co, act, mode = case
+    m = R.seeded((G, C), 11).requires_grad_(True)
+    w1 = R.seeded((Hd, C), 12, C ** -0.5).requires_grad_(True)
+    b1 = R.seeded((Hd,), 13, 0.1).requires_grad_(True)
+    w2 = R.seeded((Co, Hd), 14, Hd ** -0.5).requires_grad_(True)
+    b2 = R.seeded((Co,), 15, 0.1).requires_grad_(True)
+    dout = R.seeded((G, Co), 16)
+    z1 = F.relu(F.linear(m, w1, b1)) if act == "relu" else F.gelu(F.linear(m, w1, b1))
+    z2 = F.linear(z1, w2, b2)
+    want = torch.sigmoid(z2) if mode == 0 else z2.reshape(G, Co // 3, 3).softmax(-1).reshape(G, Co)
+    grads = torch.autograd.grad(want, (m, w1, b1, w2, b2), dout)
+    code = hip.ACT_RELU if act == "relu" else hip.ACT_GELU
+    dev = lambda t: t.detach().cuda()
+    pre, out = K.se_mlp_forward(dev(m), dev(w1), dev(b1), dev(w2), dev(b2), code, mode)
+    assert float((out.cpu() - want.detach()).abs().max()) <= 2e-6
+    got = K.se_mlp_backward(dout.cuda(), out, dev(m), pre, dev(w1), dev(w2), code, mode, 0.25)
+    for g, w, name, sc in zip(got, grads, ("dm", "dw1", "db1", "dw2", "db2"), (0.25, 1, 1, 1, 1)):
+        err = float((g.cpu() - sc * w).abs().max())
+        assert err <= 1e-5 * max(1.0, float(w.abs().max())), f"{name}: {err}"

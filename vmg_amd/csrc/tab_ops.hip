@@ -200,7 +200,161 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ src,
   }
 }
 
+// ---- squeeze-excite MLP on pooled vectors: CALayer.conv_du (reference models/function.py:542-558: 1x1 conv, ReLU, 1x1 conv, sigmoid)
+// and Enhanced_MorphFCs_decay.reweight (models/function.py:791-793: Linear, GELU, Linear, softmax over the three branches), fp32.
+// G pooled rows of C channels -> hidden Hd -> Co outputs.  The whole problem is a few hundred thousand MACs: one launch forward (a
+// workgroup per row), two backward (rows, then parameters) replace chains of ~12 / ~25 elementwise and GEMM launches.  (A single
+// 1024-thread workgroup doing all rows took 45 / 76 us: every phase is a chain of dependent L2 latencies.)
+__device__ __forceinline__ float se_act(float x, int act) { return act == 1 ? fmaxf(x, 0.f) : 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float se_dact(float x, int act) {
+  return act == 1 ? (x > 0.f ? 1.f : 0.f) : 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// pre (G, Hd) = W1 m + b1;  out (G, Co) = sigmoid(W2 act(pre) + b2)  (mode 0)  or softmax over consecutive triples (mode 1).
+// One workgroup per pooled row; LDS: the row m (C floats) and act(pre) (Hd floats).
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pre,
+                                                         float* __restrict__ out, int C, int Hd, int Co, int act1, int mode) {
+  extern __shared__ float sm[];
+  float* mrow = sm;       // C
+  float* z1 = sm + C;     // Hd
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) mrow[c] = m[(long long)g * C + c];
+  __syncthreads();
+  for (int j = wave; j < Hd; j += 4) {  // a wave per hidden unit: lanes stride over the C inputs (coalesced W1 row)
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[(long long)j * C + c] * mrow[c];
+    s = wave_sum(s) + (b1 ? b1[j] : 0.f);
+    if (lane == 0) { pre[(long long)g * Hd + j] = s; z1[j] = se_act(s, act1); }
+  }
+  __syncthreads();
+  if (mode == 0) {
+    for (int o = tid; o < Co; o += 256) {
+      float s = b2 ? b2[o] : 0.f;
+      const float* wr = w2 + (long long)o * Hd;
+      for (int j = 0; j < Hd; ++j) s += wr[j] * z1[j];
+      out[(long long)g * Co + o] = 1.f / (1.f + expf(-s));
+    }
+  } else {
+    for (int c = tid; c < Co / 3; c += 256) {
+      float z[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int o = 3 * c + k;
+        float s = b2 ? b2[o] : 0.f;
+        const float* wr = w2 + (long long)o * Hd;
+        for (int j = 0; j < Hd; ++j) s += wr[j] * z1[j];
+        z[k] = s;
+      }
+      const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+      const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx), e2 = expf(z[2] - mx), inv = 1.f / (e0 + e1 + e2);
+      float* orow = out + (long long)g * Co + 3 * c;
+      orow[0] = e0 * inv; orow[1] = e1 * inv; orow[2] = e2 * inv;
+    }
+  }
+}
+
+// Backward, row part (one workgroup per pooled row): dz2 = d(out)/d(logits) applied to dout, dz1 = (dz2 W2) * act'(pre), dm = dm_scale * dz1 W1.
+// dz2 (G, Co) and dz1 (G, Hd) go to the workspace for the parameter-gradient kernel.
+__global__ __launch_bounds__(256) void se_mlp_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              const float* __restrict__ pre, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2, float* __restrict__ dm, float* __restrict__ ws, int G,
+                                                              int C, int Hd, int Co, int act1, int mode, float dm_scale) {
+  extern __shared__ float sm[];
+  float* dz2 = sm;        // Co
+  float* dz1 = sm + Co;   // Hd
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* gz2 = ws + (long long)g * Co;
+  float* gz1 = ws + (long long)G * Co + (long long)g * Hd;
+  const float* orow = out + (long long)g * Co;
+  const float* drow = dout + (long long)g * Co;
+  if (mode == 0) {
+    for (int o = tid; o < Co; o += 256) { const float v = drow[o] * orow[o] * (1.f - orow[o]); dz2[o] = v; gz2[o] = v; }
+  } else {
+    for (int c = tid; c < Co / 3; c += 256) {
+      const float a0 = orow[3 * c], a1 = orow[3 * c + 1], a2 = orow[3 * c + 2];
+      const float d0 = drow[3 * c], d1 = drow[3 * c + 1], d2 = drow[3 * c + 2];
+      const float sd = a0 * d0 + a1 * d1 + a2 * d2;
+      const float v0 = a0 * (d0 - sd), v1 = a1 * (d1 - sd), v2 = a2 * (d2 - sd);
+      dz2[3 * c] = v0; dz2[3 * c + 1] = v1; dz2[3 * c + 2] = v2;
+      gz2[3 * c] = v0; gz2[3 * c + 1] = v1; gz2[3 * c + 2] = v2;
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < Hd; j += 4) {  // lanes stride over the Co outputs (column j of W2: a gather, served by L2)
+    float s = 0.f;
+    for (int o = lane; o < Co; o += 64) s += dz2[o] * w2[(long long)o * Hd + j];
+    s = wave_sum(s) * se_dact(pre[(long long)g * Hd + j], act1);
+    if (lane == 0) { dz1[j] = s; gz1[j] = s; }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < Hd; ++j) s += dz1[j] * w1[(long long)j * C + c];
+    dm[(long long)g * C + c] = s * dm_scale;
+  }
+}
+
+// Backward, parameter part: one thread per element of dw1 (Hd, C), dw2 (Co, Hd), db1, db2, summing over the G rows in order (deterministic).
+__global__ __launch_bounds__(256) void se_mlp_bwd_params_kernel(const float* __restrict__ m, const float* __restrict__ pre, const float* __restrict__ ws,
+                                                                float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                                float* __restrict__ db2, int G, int C, int Hd, int Co, int act1) {
+  const float* dz2 = ws;
+  const float* dz1 = ws + (long long)G * Co;
+  const int n1 = Hd * C, n2 = Co * Hd;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  if (i < n1) {
+    const int j = i / C, c = i - j * C;
+    for (int g = 0; g < G; ++g) s += dz1[g * Hd + j] * m[(long long)g * C + c];
+    dw1[i] = s;
+  } else if (i < n1 + n2) {
+    const int e = i - n1, o = e / Hd, j = e - o * Hd;
+    for (int g = 0; g < G; ++g) s += dz2[(long long)g * Co + o] * se_act(pre[g * Hd + j], act1);
+    dw2[e] = s;
+  } else if (i < n1 + n2 + Hd) {
+    const int j = i - n1 - n2;
+    for (int g = 0; g < G; ++g) s += dz1[g * Hd + j];
+    db1[j] = s;
+  } else if (i < n1 + n2 + Hd + Co) {
+    const int o = i - n1 - n2 - Hd;
+    for (int g = 0; g < G; ++g) s += dz2[(long long)g * Co + o];
+    db2[o] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int vmg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* pre, float* out, int G,
+                              int C, int Hd, int Co, int act1, int mode, void* stream) {
+  VMG_CHECK(m && w1 && w2 && pre && out && G > 0 && C > 0 && Hd > 0 && Co > 0, "se_mlp_fwd: bad arguments");
+  VMG_CHECK((act1 == 1 || act1 == 3) && (mode == 0 || (mode == 1 && Co % 3 == 0)), "se_mlp_fwd: act1 is ReLU (1) or GELU (3); mode 1 needs Co = 3 * channels");
+  VMG_CHECK((C + Hd) * 4 <= 64 * 1024, "se_mlp_fwd: C + Hd too large");
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(G), dim3(256), (C + Hd) * 4, (hipStream_t)stream, m, w1, b1, w2, b2, pre, out, C, Hd, Co, act1, mode);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_se_mlp_bwd(const float* dout, const float* out, const float* m, const float* pre, const float* w1, const float* w2, float* dm,
+                              float* dw1, float* db1, float* dw2, float* db2, float* ws, int G, int C, int Hd, int Co, int act1, int mode,
+                              float dm_scale, void* stream) {
+  VMG_CHECK(dout && out && m && pre && w1 && w2 && dm && dw1 && db1 && dw2 && db2 && ws && G > 0 && C > 0 && Hd > 0 && Co > 0, "se_mlp_bwd: bad arguments");
+  VMG_CHECK((act1 == 1 || act1 == 3) && (mode == 0 || (mode == 1 && Co % 3 == 0)), "se_mlp_bwd: act1 is ReLU (1) or GELU (3); mode 1 needs Co = 3 * channels");
+  VMG_CHECK((Co + Hd) * 4 <= 64 * 1024, "se_mlp_bwd: Co + Hd too large");
+  hipLaunchKernelGGL(se_mlp_bwd_rows_kernel, dim3(G), dim3(256), (Co + Hd) * 4, (hipStream_t)stream, dout, out, pre, w1, w2, dm, ws, G, C, Hd, Co, act1,
+                     mode, dm_scale);
+  VMG_LAUNCH_CHECK();
+  const int total = Hd * C + Co * Hd + Hd + Co;
+  hipLaunchKernelGGL(se_mlp_bwd_params_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, m, pre, (const float*)ws, dw1, db1, dw2, db2, G,
+                     C, Hd, Co, act1);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vmg_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int f, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "maxpool_fwd: bad dtype");

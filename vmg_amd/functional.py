@@ -568,28 +568,23 @@ class _ChannelAttention(torch.autograd.Function):
         r, x = r.contiguous(), x.contiguous()
         N, C = r.shape[0], r.shape[-1]
         R = r.numel() // (N * C)
-        w1m, w2m = w1.flatten(1), w2.flatten(1)
         m = K.group_reduce(r, N, scale=1.0 / R)
-        z1 = torch.relu(torch.addmm(b1, m, w1m.t()))
-        g = torch.sigmoid(torch.addmm(b2, z1, w2m.t()))
+        pre, g = K.se_mlp_forward(m, w1.flatten(1), b1, w2.flatten(1), b2, hip.ACT_RELU, 0)
         out = K.tab_elementwise(K.OP_CA_FWD, r, x, coef=g, s=s, G=N)
         ctx.s, ctx.R = s, R
-        ctx.save_for_backward(r, g, m, z1, w1, w2)
+        ctx.save_for_backward(r, g, m, pre, w1, w2)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        r, g, m, z1, w1, w2 = ctx.saved_tensors
+        r, g, m, pre, w1, w2 = ctx.saved_tensors
         s, R = ctx.s, ctx.R
         dy = dy.contiguous()
         N = r.shape[0]
-        w1m, w2m = w1.flatten(1), w2.flatten(1)
         dg = K.group_reduce(dy, N, b=r, mode=1, scale=s)          # d out / d g summed over pixels
-        dz2 = dg * g * (1 - g)
-        dz1 = (dz2 @ w2m) * (z1 > 0)
-        dm = dz1 @ w1m                                             # gradient of the GAP output
-        d_r, d_x = K.tab_elementwise(K.OP_CA_BWD, dy, coef=g, add=(dm / R).contiguous(), s=s, G=N, nout=2)
-        return (d_r, d_x, (dz1.t() @ m).reshape(w1.shape), dz1.sum(0), (dz2.t() @ z1).reshape(w2.shape), dz2.sum(0), None)
+        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(dg, g, m, pre, w1.flatten(1), w2.flatten(1), hip.ACT_RELU, 0, 1.0 / R)  # dm: gradient of the GAP output / R
+        d_r, d_x = K.tab_elementwise(K.OP_CA_BWD, dy, coef=g, add=dm, s=s, G=N, nout=2)
+        return (d_r, d_x, dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None)
 
 
 def channel_attention_residual(r, x, w1, b1, w2, b2, out_scale: float):
@@ -640,28 +635,22 @@ class _ReweightMix(torch.autograd.Function):
         B, C = h.shape[0], h.shape[-1]
         R = h.numel() // (B * C)
         m = K.group_reduce(h, B, b=w, c3=c, scale=1.0 / R)
-        pre = torch.addmm(fc1b, m, fc1w.t())
-        u = torch.nn.functional.gelu(pre)
-        a = torch.addmm(fc2b, u, fc2w.t()).reshape(B, C, 3).softmax(-1).contiguous()
+        pre, a = K.se_mlp_forward(m, fc1w, fc1b, fc2w, fc2b, hip.ACT_GELU, 1)  # a (B, 3C) = (B, C, 3): softmax over each channel's three logits
         y = K.tab_elementwise(K.OP_MIX_FWD, h, w, c, coef=a, G=B)
         ctx.R = R
-        ctx.save_for_backward(h, w, c, a, m, pre, u, fc1w, fc2w)
+        ctx.save_for_backward(h, w, c, a, m, pre, fc1w, fc2w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        h, w, c, a, m, pre, u, fc1w, fc2w = ctx.saved_tensors
+        h, w, c, a, m, pre, fc1w, fc2w = ctx.saved_tensors
         R = ctx.R
         dy = dy.contiguous()
         B, C = h.shape[0], h.shape[-1]
-        da = torch.stack([K.group_reduce(dy, B, b=t, mode=1) for t in (h, w, c)], -1)  # (B,C,3)
-        dv = (a * (da - (a * da).sum(-1, keepdim=True))).reshape(B, 3 * C)             # softmax backward
-        du = dv @ fc2w
-        x = pre
-        dpre = du * (0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327)
-        dm = dpre @ fc1w
-        dh, dw, dc = K.tab_elementwise(K.OP_MIX_BWD, dy, coef=a, add=(dm / R).contiguous(), G=B, nout=3)
-        return dh, dw, dc, dpre.t() @ m, dpre.sum(0), dv.t() @ u, dv.sum(0)
+        da = torch.stack([K.group_reduce(dy, B, b=t, mode=1) for t in (h, w, c)], -1).reshape(B, 3 * C)  # (B,C,3)
+        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(da, a, m, pre, fc1w, fc2w, hip.ACT_GELU, 1, 1.0 / R)   # softmax, Linear, GELU, Linear backward
+        dh, dw, dc = K.tab_elementwise(K.OP_MIX_BWD, dy, coef=a, add=dm, G=B, nout=3)
+        return dh, dw, dc, dw1, db1, dw2, db2
 
 
 def reweight_mix(h, w, c, fc1w, fc1b, fc2w, fc2b):

@@ -74,6 +74,8 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_void_p]),
     "vmg_win3d_attn_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_se_mlp_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+    "vmg_se_mlp_bwd": (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.c_float, c_void_p]),
     "vmg_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_maxpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_avgpool2_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -673,3 +673,42 @@ def tab_elementwise(op: int, p0, p1=None, p2=None, coef=None, add=None, s: float
     hip.check(hip.lib().vmg_tab_elementwise(hip.dtype_code(p0.dtype), op, ptr(p0), ptr(p1), ptr(p2), ptr(coef), ptr(add), s, ptr(o[0]),
                                             ptr(o[1]), ptr(o[2]), rows, rows // G, C, hip.stream_ptr()), "vmg_tab_elementwise")
     return outs[0] if nout == 1 else outs
+
+
+def se_mlp_forward(m: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, act1: int, mode: int):
+    """Squeeze-excite MLP on pooled rows m (G, C) fp32: returns (pre (G, Hd), out (G, Co)); mode 0 sigmoid, mode 1 softmax over triples."""
+    hip.require_cuda(m, w1, w2)
+    G, C = m.shape
+    Hd, Co = w1.shape[0], w2.shape[0]
+    for t in (m, w1, w2, b1, b2):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise HipError("se_mlp: contiguous fp32 tensors only")
+    pre = torch.empty(G, Hd, dtype=torch.float32, device=m.device)
+    out = torch.empty(G, Co, dtype=torch.float32, device=m.device)
+    hip.check(hip.lib().vmg_se_mlp_fwd(m.data_ptr(), w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
+                                       b2.data_ptr() if b2 is not None else None, pre.data_ptr(), out.data_ptr(), G, C, Hd, Co, act1, mode,
+                                       hip.stream_ptr()), "vmg_se_mlp_fwd")
+    return pre, out
+
+
+def se_mlp_backward(dout: torch.Tensor, out: torch.Tensor, m: torch.Tensor, pre: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, act1: int,
+                    mode: int, dm_scale: float):
+    """-> dm (G, C) * dm_scale, dw1, db1, dw2, db2 (fresh tensors)."""
+    hip.require_cuda(dout, out, m, pre, w1, w2)
+    G, C = m.shape
+    Hd, Co = w1.shape[0], w2.shape[0]
+    for t in (dout, out, m, pre, w1, w2):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise HipError("se_mlp: contiguous fp32 tensors only")
+    dev = m.device
+    buf = torch.empty(G * C + Hd * C + Hd + Co * Hd + Co + G * (Co + Hd), dtype=torch.float32, device=dev)
+    o = 0
+    parts = []
+    for n in (G * C, Hd * C, Hd, Co * Hd, Co, G * (Co + Hd)):
+        parts.append(buf[o:o + n])
+        o += n
+    dm, dw1, db1, dw2, db2, ws = parts
+    hip.check(hip.lib().vmg_se_mlp_bwd(dout.data_ptr(), out.data_ptr(), m.data_ptr(), pre.data_ptr(), w1.data_ptr(), w2.data_ptr(), dm.data_ptr(),
+                                       dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), G, C, Hd, Co, act1, mode,
+                                       float(dm_scale), hip.stream_ptr()), "vmg_se_mlp_bwd")
+    return dm.view(G, C), dw1.view(Hd, C), db1, dw2.view(Co, Hd), db2
