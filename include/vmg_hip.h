@@ -159,6 +159,17 @@ typedef struct vmg_chain_desc {
 int vmg_resblock_chain_fwd(const vmg_chain_desc* d, void* stream);
 int vmg_resblock_chain_bwd(const vmg_chain_desc* d, void* stream);
 
+/* ---- batched packing: after an optimizer step every weight needs its packs rebuilt -- ~390 launches of 4 us in VMG-REDS-few_levels.
+ * A PLAN is an array of vmg_pack_entry_bytes()-sized opaque entries in DEVICE memory, each holding the arguments of one
+ * vmg_conv_pack (kind 0) / vmg_convws_pack (kind 1) call.  vmg_pack_entry fills one entry in HOST memory (the caller copies the array to
+ * the device once; it stays valid while the weight and pack buffers stay where they are) and returns the number of 256-thread blocks the
+ * entry wants (> 0; negative: error); blk0 = sum of the block counts of the entries before it.  vmg_pack_run repacks all of them in ONE
+ * launch of total_blocks blocks. */
+int vmg_pack_entry_bytes(void);
+int vmg_pack_entry(void* entry, int kind, int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                   const int* src_ch, int transpose_flip, int cout_tiles, void* packed, int blk0);
+int vmg_pack_run(const void* plan_dev, int n, int total_blocks, void* stream);
+
 /* diagnostics: when buf is non-null the k-split variant writes 8 wave-level 100-MHz time stamps per wave
  * (uint64[workgroups][4][8]) at its phase boundaries; null switches it off */
 int vmg_conv_debug_stamps(void* buf);

@@ -493,3 +493,33 @@ def test_conv7x7_wgrad_slab_kernel(shape):
     dW2, db2 = dW0.cuda(), db0.cuda()
     K.conv_wgrad_batched([x.cuda().to(dt) for x in xs], [d.cuda().to(dt) for d in dys], dW2, db2, 7, N, H, W, scale=0.5)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)  # slabs are summed in a fixed order
+
+
+def test_repack_all_equals_individual_packs():
+    """The one-launch repack plan (vmg_pack_entry / vmg_pack_run) rebuilds exactly the bytes the single pack calls produce: forward and
+    data-gradient packs, both layouts, fp32 and bf16, 1x1 / 3x3 / 7x7, a channel slice, after an 'optimizer step' that rewrote the weights."""
+    hip, K, O, R = _setup()
+    from vmg_amd import functional as FH
+    FH.clear_pack_cache()
+    ws = [R.seeded((144, 144, 3, 3), 1).cuda(), R.seeded((144, 288, 3, 3), 2).cuda(), R.seeded((64, 32, 7, 7), 3).cuda(),
+          R.seeded((576, 144), 4).cuda(), R.seeded((48, 144, 3, 3), 5).cuda()]
+    reqs = [(ws[0], torch.bfloat16, "fwd", None, 0, None, 9, 3), (ws[0], torch.bfloat16, "dgrad", None, 0, None, 9, 3),
+            (ws[1], torch.bfloat16, "fwd", [144, 144], 0, None, 9, 3), (ws[1], torch.bfloat16, "dgrad", None, 144, 144, 9, 3),
+            (ws[2], torch.bfloat16, "fwd", None, 0, None, None, 0), (ws[2], torch.float32, "dgrad", None, 0, None, None, 0),
+            (ws[3], torch.bfloat16, "fwd", None, 0, None, None, 0), (ws[3], torch.float32, "fwd", None, 0, None, None, 0),
+            (ws[4], torch.bfloat16, "fwd", None, 0, None, 3, 2)]
+    first = [FH.packed(w, dt, kind, src_ch=sc, i0=i0, on=on, tiles=tiles, deep=deep) for (w, dt, kind, sc, i0, on, tiles, deep) in reqs]
+    before = [p.buf.clone() for p in first]
+    for w in ws:
+        w.mul_(0.5).add_(0.01)  # "optimizer step"
+    FH.bump_weight_epoch()
+    FH.repack_all()
+    again = [FH.packed(w, dt, kind, src_ch=sc, i0=i0, on=on, tiles=tiles, deep=deep) for (w, dt, kind, sc, i0, on, tiles, deep) in reqs]
+    for a, b in zip(first, again):
+        assert a is b  # cache hit: repack_all refreshed the entries in place
+    FH.clear_pack_cache()
+    fresh = [FH.packed(w, dt, kind, src_ch=sc, i0=i0, on=on, tiles=tiles, deep=deep) for (w, dt, kind, sc, i0, on, tiles, deep) in reqs]
+    for i, (a, f, b0) in enumerate(zip(again, fresh, before)):
+        assert torch.equal(a.buf, f.buf), f"pack {i} differs from the individually packed one"
+        assert not torch.equal(a.buf, b0), f"pack {i} was not rebuilt"
+    FH.clear_pack_cache()

@@ -1296,71 +1296,109 @@ struct PackK {
   short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_st0[MAX_ISRC], src_nst[MAX_ISRC];
 };
 
+// one packed element of [cout block][stage][stage image]; a stage image is [k-step j][chunk g][co][8] followed by zero padding up to
+// the 4-KiB-aligned stage stride
 template <typename T>
-__global__ void conv_pack_kernel(const PackK p) {
-  // one thread per packed element of [cout block][stage][stage image]; a stage image is [k-step j][chunk g][co][8]
-  // followed by zero padding up to the 4-KiB-aligned stage stride
-  const long long total = (long long)p.ncb * p.nstages * p.ss_elems;
+__device__ __forceinline__ void pack_std_elem(const PackK& p, long long i) {
   const int KK = p.ks * p.ks, KSTG = kstg(p.ks);
   const int body = KSTG * 4 * p.cob * 8;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int within = (int)(i % p.ss_elems);
-    long long r = i / p.ss_elems;
-    const int stage = (int)(r % p.nstages);
-    const int cb = (int)(r / p.nstages);
-    float v = 0.f;
-    if (within < body) {
-      const int e = within & 7;
-      int t = within >> 3;
-      const int co = t % p.cob;
-      t /= p.cob;
-      const int g = t & 3, j = t >> 2;
-      int s = 0;
-      while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
-      const int sl = stage - p.src_st0[s];
-      const int CH = p.src_ch[s] >> 3;
-      int tap, q;
-      if (p.ks > 1) { const int cbk = sl / p.ks, ky = sl - p.ks * cbk; tap = ky * p.ks + j; q = 4 * cbk + g; }
-      else { tap = 0; q = 4 * (2 * sl + j) + g; }
-      const int col = cb * p.cob + co;  // output channel within [0, on)
-      if (q < CH && col < p.on) {
-        const int kc = p.src_off[s] + q * 8 + e;  // K-side channel
-        const int oc = p.o0 + col;                // output-side channel
-        if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
-        else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
-      }
+  const int within = (int)(i % p.ss_elems);
+  long long r = i / p.ss_elems;
+  const int stage = (int)(r % p.nstages);
+  const int cb = (int)(r / p.nstages);
+  float v = 0.f;
+  if (within < body) {
+    const int e = within & 7;
+    int t = within >> 3;
+    const int co = t % p.cob;
+    t /= p.cob;
+    const int g = t & 3, j = t >> 2;
+    int s = 0;
+    while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
+    const int sl = stage - p.src_st0[s];
+    const int CH = p.src_ch[s] >> 3;
+    int tap, q;
+    if (p.ks > 1) { const int cbk = sl / p.ks, ky = sl - p.ks * cbk; tap = ky * p.ks + j; q = 4 * cbk + g; }
+    else { tap = 0; q = 4 * (2 * sl + j) + g; }
+    const int col = cb * p.cob + co;  // output channel within [0, on)
+    if (q < CH && col < p.on) {
+      const int kc = p.src_off[s] + q * 8 + e;  // K-side channel
+      const int oc = p.o0 + col;                // output-side channel
+      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
+      else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
     }
-    reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
   }
+  reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ void conv_pack_kernel(const PackK p) {
+  const long long total = (long long)p.ncb * p.nstages * p.ss_elems;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) pack_std_elem<T>(p, i);
 }
 
 // weight-streaming layout: [cout block][stage][k-step jj 0..2][lane group g][co][8] bf16, K slots by ws_slot()
-__global__ void convws_pack_kernel(const PackK p) {
-  const int KSE = 4 * p.cob * 8;  // elements per k-step
-  const long long total = (long long)p.ncb * p.nstages * 3 * KSE;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    long long t = i >> 3;
-    const int co = (int)(t % p.cob); t /= p.cob;
-    const int g = (int)(t & 3); t >>= 2;
-    const int jj = (int)(t % 3); t /= 3;
-    const int stage = (int)(t % p.nstages);
-    const int cb = (int)(t / p.nstages);
-    int s = 0;
-    while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
-    const int j = (stage - p.src_st0[s]) * 3 + jj;
-    int tap, chunk;
-    ws_slot(p.src_ch[s] >> 3, j, g, tap, chunk);
-    const int col = cb * p.cob + co;
-    float v = 0.f;
-    if (tap >= 0 && col < p.on) {
-      const int kc = p.src_off[s] + chunk * 8 + e;
-      const int oc = p.o0 + col;
-      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * 9 + tap];
-      else v = p.w[((long long)kc * p.I + oc) * 9 + (8 - tap)];
-    }
-    reinterpret_cast<bf16*>(p.out)[i] = (bf16)v;
+__device__ __forceinline__ void pack_ws_elem(const PackK& p, long long i) {
+  const int e = (int)(i & 7);
+  long long t = i >> 3;
+  const int co = (int)(t % p.cob); t /= p.cob;
+  const int g = (int)(t & 3); t >>= 2;
+  const int jj = (int)(t % 3); t /= 3;
+  const int stage = (int)(t % p.nstages);
+  const int cb = (int)(t / p.nstages);
+  int s = 0;
+  while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
+  const int j = (stage - p.src_st0[s]) * 3 + jj;
+  int tap, chunk;
+  ws_slot(p.src_ch[s] >> 3, j, g, tap, chunk);
+  const int col = cb * p.cob + co;
+  float v = 0.f;
+  if (tap >= 0 && col < p.on) {
+    const int kc = p.src_off[s] + chunk * 8 + e;
+    const int oc = p.o0 + col;
+    if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * 9 + tap];
+    else v = p.w[((long long)kc * p.I + oc) * 9 + (8 - tap)];
   }
+  reinterpret_cast<bf16*>(p.out)[i] = (bf16)v;
+}
+
+__global__ void convws_pack_kernel(const PackK p) {
+  const long long total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) pack_ws_elem(p, i);
+}
+
+// A PLAN of packs run by one launch (every weight of a network after an optimizer step): entry e owns blocks [blk0, blk0 + nblk).
+struct PackEntry {
+  PackK p;
+  long long total;  // elements
+  int kind;         // 0: vmg_conv_pack layout, 1: vmg_convws_pack layout
+  int dtype;
+  int blk0, nblk;
+};
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __restrict__ plan, int n) {
+  __shared__ PackEntry ent;
+  __shared__ int which;
+  if (threadIdx.x == 0) {  // the entry whose block range holds blockIdx.x
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (plan[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    which = lo;
+  }
+  __syncthreads();
+  {
+    const int* src = reinterpret_cast<const int*>(plan + which);
+    int* dst = reinterpret_cast<int*>(&ent);
+    for (int k = threadIdx.x; k < (int)(sizeof(PackEntry) / 4); k += 256) dst[k] = src[k];
+  }
+  __syncthreads();
+  const long long stride = (long long)ent.nblk * 256;
+  long long i = (long long)((int)blockIdx.x - ent.blk0) * 256 + threadIdx.x;
+  if (ent.kind == 1) { for (; i < ent.total; i += stride) pack_ws_elem(ent.p, i); }
+  else if (ent.dtype == VMG_BF16) { for (; i < ent.total; i += stride) pack_std_elem<bf16>(ent.p, i); }
+  else { for (; i < ent.total; i += stride) pack_std_elem<float>(ent.p, i); }
 }
 
 // internal channel-block splitting: the SAME rule for packing and for the conv call
@@ -1567,13 +1605,14 @@ extern "C" int64_t vmg_conv_pack_bytes(int dtype, int ks, int on, int nsrc, cons
   return (int64_t)ncb * nst * stage_stride(ks, cout_tiles, dtype == VMG_BF16 ? 16 : 32);
 }
 
-extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
-                             const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream) {
+static int fill_pack_std(PackK& p, long long& total, int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                         const int* src_ch, int transpose_flip, int cout_tiles, void* packed) {
+  VMG_CHECK(w && packed, "conv_pack: null pointer");
   VMG_CHECK(ks == 1 || ks == 3 || ks == 7, "conv_pack: ks must be 1, 3 or 7");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_pack: bad dtype");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "conv_pack: nsrc must be 1..4");
   VMG_CHECK(!transpose_flip || nsrc == 1, "conv_pack: data-gradient packing takes one K slice");
-  PackK p;
+  VMG_CHECK(cout_tiles >= 1 && cout_tiles <= 9, "conv_pack: cout_tiles must be 1..9");
   memset(&p, 0, sizeof(p));
   const int n = expand_sources(nsrc, src_off, src_ch, p.src_off, p.src_ch, nullptr);
   VMG_CHECK(n > 0, "conv_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
@@ -1591,7 +1630,16 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.nstages = st;
   const int es = dtype == VMG_BF16 ? 2 : 4;
   p.ss_elems = stage_stride(ks, cout_tiles, es * 8) / es;
-  const long long total = (long long)p.ncb * p.nstages * p.ss_elems;
+  total = (long long)p.ncb * p.nstages * p.ss_elems;
+  return 0;
+}
+
+extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                             const int* src_ch, int transpose_flip, int cout_tiles, void* packed, void* stream) {
+  PackK p;
+  long long total = 0;
+  const int rc = fill_pack_std(p, total, dtype, w, O, I, ks, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
+  if (rc) return rc;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -1621,13 +1669,12 @@ extern "C" int64_t vmg_convws_pack_bytes(int on, int nsrc, const int* src_ch, in
   return (int64_t)cdiv(on, cob) * p.nstages * 3 * (int64_t)cob * 64;
 }
 
-extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch,
-                               int transpose_flip, int cout_tiles, void* packed, void* stream) {
+static int fill_pack_ws(PackK& p, long long& total, const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch,
+                        int transpose_flip, int cout_tiles, void* packed) {
   VMG_CHECK(w && packed, "convws_pack: null pointer");
   VMG_CHECK(cout_tiles == 7 || cout_tiles == 9, "convws_pack: cout_tiles must be 7 or 9");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "convws_pack: nsrc must be 1..4");
   VMG_CHECK(!transpose_flip || nsrc == 1, "convws_pack: data-gradient packing takes one K slice");
-  PackK p;
   memset(&p, 0, sizeof(p));
   VMG_CHECK(ws_plan(nsrc, src_off, src_ch, p) > 0, "convws_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
   const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
@@ -1635,9 +1682,47 @@ extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int
   VMG_CHECK(o0 >= 0 && on > 0 && o0 + on <= odim, "convws_pack: output slice out of range");
   p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = 3; p.o0 = o0; p.on = on; p.transpose_flip = transpose_flip;
   p.cob = cout_tiles * 16; p.ncb = cdiv(on, p.cob);
-  const long long total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
+  total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
+  return 0;
+}
+
+extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch,
+                               int transpose_flip, int cout_tiles, void* packed, void* stream) {
+  PackK p;
+  long long total = 0;
+  const int rc = fill_pack_ws(p, total, w, O, I, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
+  if (rc) return rc;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(convws_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
+
+extern "C" int vmg_pack_entry(void* entry, int kind, int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
+                              const int* src_ch, int transpose_flip, int cout_tiles, void* packed, int blk0) {
+  VMG_CHECK(entry && (kind == 0 || kind == 1) && blk0 >= 0, "pack_entry: bad arguments");
+  PackEntry e;
+  memset(&e, 0, sizeof(e));
+  int rc;
+  if (kind == 1) {
+    VMG_CHECK(ks == 3 && dtype == VMG_BF16, "pack_entry: the weight-streaming layout is bf16 3x3");
+    rc = fill_pack_ws(e.p, e.total, w, O, I, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
+  } else {
+    rc = fill_pack_std(e.p, e.total, dtype, w, O, I, ks, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
+  }
+  if (rc) return rc;
+  e.kind = kind; e.dtype = dtype; e.blk0 = blk0;
+  long long nb = (e.total + 256LL * 16 - 1) / (256LL * 16);  // ~16 elements per thread
+  e.nblk = (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+  memcpy(entry, &e, sizeof(e));
+  return e.nblk;
+}
+
+extern "C" int vmg_pack_run(const void* plan_dev, int n, int total_blocks, void* stream) {
+  VMG_CHECK(plan_dev && n > 0 && total_blocks > 0, "pack_run: bad arguments");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)plan_dev, n);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -60,6 +60,8 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
         return hit[1]
+    if hit is not None and hit[0][1] == ver[1]:
+        _PACK_VOLATILE.add(key)  # modified in place between optimizer steps (the MorphFC decay, T1): repack_all leaves it alone
     w = weight.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -100,6 +102,29 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
 
 def clear_pack_cache():
     _PACK_CACHE.clear()
+    _PACK_VOLATILE.clear()
+
+
+_PACK_VOLATILE = set()
+_PACK_PLAN = K.PackPlan()
+
+
+def repack_all():
+    """Rebuild, in ONE launch, every cached pack whose source is the parameter itself (call right after the optimizer has written the
+    parameters): the next forward finds them current instead of launching ~390 small pack kernels one by one."""
+    live, packs = [], []
+    for key, (ver, pw, weight) in _PACK_CACHE.items():
+        if key in _PACK_VOLATILE or pw.call is None or pw.call[0] != weight.data_ptr():
+            continue  # (a zero-padded copy was packed, not the parameter: the on-demand path redoes it)
+        live.append(key)
+        packs.append(pw)
+    if not packs:
+        return
+    _PACK_PLAN.run(packs)
+    ep = _WEIGHT_EPOCH[0]
+    for key in live:
+        _, pw, weight = _PACK_CACHE[key]
+        _PACK_CACHE[key] = ((weight._version, ep), pw, weight)
 
 
 def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:

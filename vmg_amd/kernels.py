@@ -40,11 +40,12 @@ def cout_tiles_for(cout: int, dtype: torch.dtype = torch.bfloat16, ks: int = 3) 
 class PackedConv:
     """Packed (device) weights of one convolution / linear for one direction (forward or data-gradient)."""
 
-    __slots__ = ("buf", "dtype", "ks", "cout", "src_ch", "cout_tiles", "layout")
+    __slots__ = ("buf", "dtype", "ks", "cout", "src_ch", "cout_tiles", "layout", "call")
 
-    def __init__(self, buf, dtype, ks, cout, src_ch, cout_tiles, layout="std"):
+    def __init__(self, buf, dtype, ks, cout, src_ch, cout_tiles, layout="std", call=None):
         self.buf, self.dtype, self.ks, self.cout, self.src_ch, self.cout_tiles = buf, dtype, ks, cout, list(src_ch), cout_tiles
         self.layout = layout  # 'std': vmg_conv_pack; 'ws': vmg_convws_pack (the weight-streaming 3x3 kernel, deep = 3)
+        self.call = call      # (weight data_ptr, O, I, o0, on, src_off, src_ch, transpose_flip): what a plan entry needs to redo this pack
 
 
 def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None,
@@ -83,7 +84,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
         raise HipError("pack buffer too small")
     hip.check(l.vmg_conv_pack(code, w.data_ptr(), O, I, ks, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch),
                               1 if transpose_flip else 0, tiles, out.data_ptr(), hip.stream_ptr()), "vmg_conv_pack")
-    return PackedConv(out, dtype, ks, on, src_ch, tiles)
+    return PackedConv(out, dtype, ks, on, src_ch, tiles, call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), 1 if transpose_flip else 0))
 
 
 def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -> int:
@@ -130,7 +131,8 @@ def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None,
     out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     hip.check(l.vmg_convws_pack(w.data_ptr(), O, I, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch), 1 if transpose_flip else 0,
                                 cout_tiles, out.data_ptr(), hip.stream_ptr()), "vmg_convws_pack")
-    return PackedConv(out, torch.bfloat16, 3, on, src_ch, cout_tiles, layout="ws")
+    return PackedConv(out, torch.bfloat16, 3, on, src_ch, cout_tiles, layout="ws",
+                      call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), 1 if transpose_flip else 0))
 
 
 # vmg_conv_desc as one struct format (checked against the ctypes layout at import): field order of hip.ConvDesc
@@ -712,3 +714,33 @@ def se_mlp_backward(dout: torch.Tensor, out: torch.Tensor, m: torch.Tensor, pre:
                                        dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), G, C, Hd, Co, act1, mode,
                                        float(dm_scale), hip.stream_ptr()), "vmg_se_mlp_bwd")
     return dm.view(G, C), dw1.view(Hd, C), db1, dw2.view(Co, Hd), db2
+
+
+class PackPlan:
+    """One-launch repacking of many weights (vmg_pack_entry / vmg_pack_run): the entry array lives on the device and is rebuilt only
+    when the set of packs (or a weight's / pack buffer's address) changes."""
+
+    def __init__(self):
+        self.sig, self.dev, self.n, self.blocks = None, None, 0, 0
+
+    def run(self, packs: Sequence[PackedConv]):
+        packs = [p for p in packs if p.call is not None]
+        if not packs:
+            return
+        sig = tuple((p.call[0], p.buf.data_ptr()) for p in packs)
+        l = hip.lib()
+        if sig != self.sig:
+            esz = l.vmg_pack_entry_bytes()
+            host = (ctypes.c_char * (esz * len(packs)))()
+            base = ctypes.addressof(host)
+            blk = 0
+            for i, p in enumerate(packs):
+                wptr, O, I, o0, on, soff, sch, tf = p.call
+                nb = l.vmg_pack_entry(base + i * esz, 1 if p.layout == "ws" else 0, hip.dtype_code(p.dtype), wptr, O, I, p.ks, o0, on, len(sch),
+                                      _intarr(soff), _intarr(sch), tf, p.cout_tiles, p.buf.data_ptr(), blk)
+                if nb <= 0:
+                    hip.check(nb if nb < 0 else -1, "vmg_pack_entry")
+                blk += nb
+            self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(packs[0].buf.device)
+            self.sig, self.n, self.blocks = sig, len(packs), blk
+        hip.check(l.vmg_pack_run(self.dev.data_ptr(), self.n, self.blocks, hip.stream_ptr()), "vmg_pack_run")

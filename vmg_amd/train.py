@@ -521,6 +521,7 @@ class TrainStep:
             self.opt.launch()
             from . import functional as FH
             FH.bump_weight_epoch()  # the kernel rewrote the parameters behind autograd's version counters
+            FH.repack_all()         # ... and every weight pack is rebuilt by one launch
         else:
             self.opt.step()
         self.opt.zero_grad(set_to_none=True)
