@@ -324,13 +324,13 @@ int vmg_maxpool_bwd(int dtype, const void* dy, const unsigned char* idx, void* d
  * Replaces CALayer.conv_du (reference: models/function.py:542-558; act1 = VMG_ACT_RELU, mode 0: out = sigmoid(W2 act(W1 m + b1) + b2))
  * and Enhanced_MorphFCs_decay.reweight + softmax (models/function.py:791-793; act1 = VMG_ACT_GELU, mode 1: Co = 3 * channels, out =
  * softmax over each channel's three consecutive logits).  w1 (Hd, C), w2 (Co, Hd) row-major; pre (G, Hd) is the saved pre-activation.
- * _bwd takes dout = dL/d out and WRITES dm (G, C) = dm_scale * dL/dm and the parameter gradients dw1, db1, dw2, db2 (not
- * accumulated); ws: G * (Co + Hd) floats of scratch. */
+ * _bwd takes dout = dL/d out and WRITES dm (G, C) = dm_scale * dL/dm; the parameter gradients dw1, db1, dw2, db2 are written
+ * (accumulate = 0) or added to what the buffers hold (accumulate = 1: straight into param.grad); ws: G * (Co + Hd) floats of scratch. */
 int vmg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* pre, float* out, int G, int C,
                    int Hd, int Co, int act1, int mode, void* stream);
 int vmg_se_mlp_bwd(const float* dout, const float* out, const float* m, const float* pre, const float* w1, const float* w2, float* dm,
                    float* dw1, float* db1, float* dw2, float* db2, float* ws, int G, int C, int Hd, int Co, int act1, int mode, float dm_scale,
-                   void* stream);
+                   int accumulate, void* stream);
 
 /* ---- SPyNet pyramid pieces (reference: models/vmg.py:39-123), channels-last -----------------------------------------------
  * vmg_avgpool2_nhwc: F.avg_pool2d(x, 2, 2) of (n, h, w, c) -> (n, h/2, w/2, c)  (:66-70).

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_rows_kernel(const float* __res
 // Backward, parameter part: one thread per element of dw1 (Hd, C), dw2 (Co, Hd), db1, db2, summing over the G rows in order (deterministic).
 __global__ __launch_bounds__(256) void se_mlp_bwd_params_kernel(const float* __restrict__ m, const float* __restrict__ pre, const float* __restrict__ ws,
                                                                 float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                                                float* __restrict__ db2, int G, int C, int Hd, int Co, int act1) {
+                                                                float* __restrict__ db2, int G, int C, int Hd, int Co, int act1, int accumulate) {
   const float* dz2 = ws;
   const float* dz1 = ws + (long long)G * Co;
   const int n1 = Hd * C, n2 = Co * Hd;
@@ -312,19 +312,19 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_params_kernel(const float* __r
   if (i < n1) {
     const int j = i / C, c = i - j * C;
     for (int g = 0; g < G; ++g) s += dz1[g * Hd + j] * m[(long long)g * C + c];
-    dw1[i] = s;
+    dw1[i] = accumulate ? dw1[i] + s : s;
   } else if (i < n1 + n2) {
     const int e = i - n1, o = e / Hd, j = e - o * Hd;
     for (int g = 0; g < G; ++g) s += dz2[(long long)g * Co + o] * se_act(pre[g * Hd + j], act1);
-    dw2[e] = s;
+    dw2[e] = accumulate ? dw2[e] + s : s;
   } else if (i < n1 + n2 + Hd) {
     const int j = i - n1 - n2;
     for (int g = 0; g < G; ++g) s += dz1[g * Hd + j];
-    db1[j] = s;
+    db1[j] = accumulate ? db1[j] + s : s;
   } else if (i < n1 + n2 + Hd + Co) {
     const int o = i - n1 - n2 - Hd;
     for (int g = 0; g < G; ++g) s += dz2[(long long)g * Co + o];
-    db2[o] = s;
+    db2[o] = accumulate ? db2[o] + s : s;
   }
 }
 
@@ -342,7 +342,7 @@ extern "C" int vmg_se_mlp_fwd(const float* m, const float* w1, const float* b1, 
 
 extern "C" int vmg_se_mlp_bwd(const float* dout, const float* out, const float* m, const float* pre, const float* w1, const float* w2, float* dm,
                               float* dw1, float* db1, float* dw2, float* db2, float* ws, int G, int C, int Hd, int Co, int act1, int mode,
-                              float dm_scale, void* stream) {
+                              float dm_scale, int accumulate, void* stream) {
   VMG_CHECK(dout && out && m && pre && w1 && w2 && dm && dw1 && db1 && dw2 && db2 && ws && G > 0 && C > 0 && Hd > 0 && Co > 0, "se_mlp_bwd: bad arguments");
   VMG_CHECK((act1 == 1 || act1 == 3) && (mode == 0 || (mode == 1 && Co % 3 == 0)), "se_mlp_bwd: act1 is ReLU (1) or GELU (3); mode 1 needs Co = 3 * channels");
   VMG_CHECK((Co + Hd) * 4 <= 64 * 1024, "se_mlp_bwd: Co + Hd too large");
@@ -351,7 +351,7 @@ extern "C" int vmg_se_mlp_bwd(const float* dout, const float* out, const float* 
   VMG_LAUNCH_CHECK();
   const int total = Hd * C + Co * Hd + Hd + Co;
   hipLaunchKernelGGL(se_mlp_bwd_params_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, m, pre, (const float*)ws, dw1, db1, dw2, db2, G,
-                     C, Hd, Co, act1);
+                     C, Hd, Co, act1, accumulate);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -180,6 +180,35 @@ class _DeferredWgrad:
             self.managed.add(id(bias))
         return self.gen
 
+    # -- small parameters (LayerNorm affine, squeeze-excite MLPs): in mode 'deferred' their backward kernels add straight into .grad
+    #    (no zero-filled temporaries, no AccumulateGrad add per parameter)
+    def direct(self, *params) -> bool:
+        return self.mode == "deferred" and all(p is not None and p.requires_grad and p.is_leaf for p in params)
+
+    def note_params(self, *params) -> int:
+        for p in params:
+            key = (self.gen, id(p))
+            self.uses[key] = self.uses.get(key, 0) + 1
+            self.managed.add(id(p))
+        return self.gen
+
+    @staticmethod
+    def grad_of(p: torch.Tensor) -> torch.Tensor:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        return p.grad
+
+    def written(self, gen: int, *params):
+        for p in params:
+            key = (gen, id(p))
+            left = self.uses.get(key, 1) - 1
+            if left <= 0:
+                self.uses.pop(key, None)
+                for cb in self.callbacks:
+                    cb(p)
+            else:
+                self.uses[key] = left
+
     def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0):
         ent = self.pending.setdefault(id(weight), [weight, bias, []])
         ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale)))
@@ -451,11 +480,18 @@ class _LayerNorm(torch.autograd.Function):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_forward(x, w, b, eps)
         ctx.save_for_backward(x, mean, rstd, w)
+        ctx.direct = DEFERRED.direct(w, b)
+        if ctx.direct:
+            ctx.params, ctx.gen = (w, b), DEFERRED.note_params(w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, w = ctx.saved_tensors
+        if ctx.direct:
+            dx, _, _ = K.layernorm_backward(dy, x, mean, rstd, w, into=tuple(DEFERRED.grad_of(p) for p in ctx.params))
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return dx, None, None, None
         dx, dw, db = K.layernorm_backward(dy, x, mean, rstd, w)
         return dx, dw, db, None
 
@@ -470,11 +506,18 @@ class _SpaceDepthLayerNorm(torch.autograd.Function):
         y, mean, rstd = K.space_depth_ln_forward(x, mode, w, b, eps)
         ctx.mode = mode
         ctx.save_for_backward(x, mean, rstd, w)
+        ctx.direct = DEFERRED.direct(w, b)
+        if ctx.direct:
+            ctx.params, ctx.gen = (w, b), DEFERRED.note_params(w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, w = ctx.saved_tensors
+        if ctx.direct:
+            dx, _, _ = K.space_depth_ln_backward(dy, x, ctx.mode, mean, rstd, w, into=tuple(DEFERRED.grad_of(p) for p in ctx.params))
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return dx, None, None, None, None
         dx, dw, db = K.space_depth_ln_backward(dy, x, ctx.mode, mean, rstd, w)
         return dx, dw, db, None, None
 
@@ -598,6 +641,9 @@ class _ChannelAttention(torch.autograd.Function):
         out = K.tab_elementwise(K.OP_CA_FWD, r, x, coef=g, s=s, G=N)
         ctx.s, ctx.R = s, R
         ctx.save_for_backward(r, g, m, pre, w1, w2)
+        ctx.direct = DEFERRED.direct(w1, b1, w2, b2)
+        if ctx.direct:
+            ctx.params, ctx.gen = (w1, b1, w2, b2), DEFERRED.note_params(w1, b1, w2, b2)
         return out
 
     @staticmethod
@@ -607,8 +653,12 @@ class _ChannelAttention(torch.autograd.Function):
         dy = dy.contiguous()
         N = r.shape[0]
         dg = K.group_reduce(dy, N, b=r, mode=1, scale=s)          # d out / d g summed over pixels
-        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(dg, g, m, pre, w1.flatten(1), w2.flatten(1), hip.ACT_RELU, 0, 1.0 / R)  # dm: gradient of the GAP output / R
+        into = tuple(DEFERRED.grad_of(p) for p in ctx.params) if ctx.direct else None
+        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(dg, g, m, pre, w1.flatten(1), w2.flatten(1), hip.ACT_RELU, 0, 1.0 / R, into=into)  # dm: gradient of the GAP output / R
         d_r, d_x = K.tab_elementwise(K.OP_CA_BWD, dy, coef=g, add=dm, s=s, G=N, nout=2)
+        if ctx.direct:
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return d_r, d_x, None, None, None, None, None
         return (d_r, d_x, dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None)
 
 
@@ -664,6 +714,9 @@ class _ReweightMix(torch.autograd.Function):
         y = K.tab_elementwise(K.OP_MIX_FWD, h, w, c, coef=a, G=B)
         ctx.R = R
         ctx.save_for_backward(h, w, c, a, m, pre, fc1w, fc2w)
+        ctx.direct = DEFERRED.direct(fc1w, fc1b, fc2w, fc2b)
+        if ctx.direct:
+            ctx.params, ctx.gen = (fc1w, fc1b, fc2w, fc2b), DEFERRED.note_params(fc1w, fc1b, fc2w, fc2b)
         return y
 
     @staticmethod
@@ -673,8 +726,12 @@ class _ReweightMix(torch.autograd.Function):
         dy = dy.contiguous()
         B, C = h.shape[0], h.shape[-1]
         da = torch.stack([K.group_reduce(dy, B, b=t, mode=1) for t in (h, w, c)], -1).reshape(B, 3 * C)  # (B,C,3)
-        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(da, a, m, pre, fc1w, fc2w, hip.ACT_GELU, 1, 1.0 / R)   # softmax, Linear, GELU, Linear backward
+        into = tuple(DEFERRED.grad_of(p) for p in ctx.params) if ctx.direct else None
+        dm, dw1, db1, dw2, db2 = K.se_mlp_backward(da, a, m, pre, fc1w, fc2w, hip.ACT_GELU, 1, 1.0 / R, into=into)   # softmax, Linear, GELU, Linear backward
         dh, dw, dc = K.tab_elementwise(K.OP_MIX_BWD, dy, coef=a, add=dm, G=B, nout=3)
+        if ctx.direct:
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return dh, dw, dc, None, None, None, None
         return dh, dw, dc, dw1, db1, dw2, db2
 
 

@@ -79,7 +79,7 @@ SIGNATURES = {
                                c_int]),
     "vmg_pack_run": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "vmg_se_mlp_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
-    "vmg_se_mlp_bwd": (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.c_float, c_void_p]),
+    "vmg_se_mlp_bwd": (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.c_float, c_int, c_void_p]),
     "vmg_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_maxpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_avgpool2_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -357,14 +357,25 @@ def layernorm_forward(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: fl
     return y, mean, rstd
 
 
-def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor):
+def _grad_pair(C: int, device, into):
+    """(dw, db) accumulators of a LayerNorm backward: fresh zeros, or the caller's fp32 buffers (param.grad) to add into."""
+    if into is None:
+        return torch.zeros(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device)
+    dw, db = into
+    for t in (dw, db):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C or not t.is_cuda:
+            raise HipError("LayerNorm gradient buffers must be contiguous fp32 (C,) on the GPU")
+    return dw, db
+
+
+def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None):
+    """into = (dw, db): the kernel's atomic sums are ADDED to these buffers (param.grad) instead of to fresh zero tensors."""
     hip.require_cuda(dy, x, mean, rstd, w)
     C = x.shape[-1]
     M = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    dw = torch.zeros(C, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dw, db = _grad_pair(C, x.device, into)
     hip.check(hip.lib().vmg_layernorm_bwd(hip.dtype_code(x.dtype), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                           w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
               "vmg_layernorm_bwd")
@@ -507,7 +518,7 @@ def space_depth_ln_forward(x: torch.Tensor, mode: str, w: torch.Tensor, b: torch
     return y, mean, rstd
 
 
-def space_depth_ln_backward(dy: torch.Tensor, x: torch.Tensor, mode: str, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor):
+def space_depth_ln_backward(dy: torch.Tensor, x: torch.Tensor, mode: str, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None):
     hip.require_cuda(dy, x, mean, rstd, w)
     N, Hi, Wi, Ci = x.shape
     if mode == "down":
@@ -516,8 +527,7 @@ def space_depth_ln_backward(dy: torch.Tensor, x: torch.Tensor, mode: str, mean: 
         H, W, cseg, C, m = 2 * Hi, 2 * Wi, Ci // 4, Ci // 4, 2
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    dw = torch.zeros(C, dtype=torch.float32, device=x.device)
-    db = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dw, db = _grad_pair(C, x.device, into)
     hip.check(hip.lib().vmg_space_depth_ln_bwd(hip.dtype_code(x.dtype), m, dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(),
                                                dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, cseg, hip.stream_ptr()), "vmg_space_depth_ln_bwd")
     return dx, dw, db
@@ -694,8 +704,9 @@ def se_mlp_forward(m: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, 
 
 
 def se_mlp_backward(dout: torch.Tensor, out: torch.Tensor, m: torch.Tensor, pre: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, act1: int,
-                    mode: int, dm_scale: float):
-    """-> dm (G, C) * dm_scale, dw1, db1, dw2, db2 (fresh tensors)."""
+                    mode: int, dm_scale: float, into=None):
+    """-> dm (G, C) * dm_scale, dw1, db1, dw2, db2 (fresh tensors); into = (gw1, gb1, gw2, gb2): the parameter gradients are ADDED to these
+    contiguous fp32 buffers (param.grad) and returned as such."""
     hip.require_cuda(dout, out, m, pre, w1, w2)
     G, C = m.shape
     Hd, Co = w1.shape[0], w2.shape[0]
@@ -703,16 +714,26 @@ def se_mlp_backward(dout: torch.Tensor, out: torch.Tensor, m: torch.Tensor, pre:
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise HipError("se_mlp: contiguous fp32 tensors only")
     dev = m.device
-    buf = torch.empty(G * C + Hd * C + Hd + Co * Hd + Co + G * (Co + Hd), dtype=torch.float32, device=dev)
+    sizes = (G * C, G * (Co + Hd)) if into is not None else (G * C, G * (Co + Hd), Hd * C, Hd, Co * Hd, Co)
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
     o = 0
     parts = []
-    for n in (G * C, Hd * C, Hd, Co * Hd, Co, G * (Co + Hd)):
+    for n in sizes:
         parts.append(buf[o:o + n])
         o += n
-    dm, dw1, db1, dw2, db2, ws = parts
+    if into is not None:
+        dm, ws = parts
+        dw1, db1, dw2, db2 = into
+        for t, n in zip(into, (Hd * C, Hd, Co * Hd, Co)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or not t.is_cuda:
+                raise HipError("se_mlp: gradient buffers must be contiguous fp32 of the parameters' sizes")
+    else:
+        dm, ws, dw1, db1, dw2, db2 = parts
     hip.check(hip.lib().vmg_se_mlp_bwd(dout.data_ptr(), out.data_ptr(), m.data_ptr(), pre.data_ptr(), w1.data_ptr(), w2.data_ptr(), dm.data_ptr(),
                                        dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), G, C, Hd, Co, act1, mode,
-                                       float(dm_scale), hip.stream_ptr()), "vmg_se_mlp_bwd")
+                                       float(dm_scale), 1 if into is not None else 0, hip.stream_ptr()), "vmg_se_mlp_bwd")
+    if into is not None:
+        return dm.view(G, C), dw1, db1, dw2, db2
     return dm.view(G, C), dw1.view(Hd, C), db1, dw2.view(Co, Hd), db2
 
 
