@@ -199,6 +199,15 @@ int64_t vmg_conv_wgrad_ws_bytes(void);
 int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
                               int64_t x_ps, int Cin, int64_t dy_ps, int Cout, float* dW, int I_total, int o0, int i0, float* db,
                               float scale, void* ws, int64_t ws_bytes, void* stream);
+/* Several weight gradients of ONE shape in one launch (bf16, 3x3, 8-channel vectors, 16-byte aligned operands): x / dy hold
+ * nprob * npairs pointers [problem][pair] (nprob <= 8, npairs <= 16), dW / db one pointer and scales one factor per problem (db or db[i]
+ * may be null): dW_i += scales[i] * sum over pairs.
+ * The 30 equal convolutions of a recurrent residual chain (reference: models/trajectory.py:16-52) complete at the same moment of the
+ * backward pass; served one per launch each cuts its pixels into ~85 K slabs to fill the chip and moves 2 x 73 MB of partial sums,
+ * served eight per launch a problem needs ~10 slabs. */
+int vmg_conv_wgrad3_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin,
+                          int64_t dy_ps, int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws,
+                          int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound, one pass, 16-byte vectors).

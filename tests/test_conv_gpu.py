@@ -523,3 +523,27 @@ def test_repack_all_equals_individual_packs():
         assert torch.equal(a.buf, f.buf), f"pack {i} differs from the individually packed one"
         assert not torch.equal(a.buf, b0), f"pack {i} was not rebuilt"
     FH.clear_pack_cache()
+
+
+def test_conv_wgrad3_multi_equals_single_launches():
+    """Eleven 3x3 weight gradients of one shape (3 pairs each, own scale, some without bias) through vmg_conv_wgrad3_multi (8 + 3 per launch)
+    against the one-problem-per-launch path on the same bf16 operands; both accumulate into an existing gradient."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, P = 2, 24, 40, 144, 144, 3
+    dt = torch.bfloat16
+    probs, single = [], []
+    for i in range(11):
+        xs = [R.seeded((N, H, W, Ci), 100 + 10 * i + p).cuda().to(dt) for p in range(P)]
+        dys = [R.seeded((N, H, W, Co), 500 + 10 * i + p).cuda().to(dt) for p in range(P)]
+        dW0, db0 = R.seeded((Co, Ci, 3, 3), 900 + i).cuda(), (R.seeded((Co,), 950 + i).cuda() if i % 3 else None)
+        scale = 0.1 if i % 2 else 1.0
+        probs.append((xs, dys, dW0.clone(), db0.clone() if db0 is not None else None, scale))
+        dW1, db1 = dW0.clone(), (db0.clone() if db0 is not None else None)
+        K.conv_wgrad_batched(xs, dys, dW1, db1, 3, N, H, W, scale=scale)
+        single.append((dW1, db1))
+    K.conv_wgrad3_multi(probs, N, H, W)
+    for i, ((_, _, dW, db, _), (dW1, db1)) in enumerate(zip(probs, single)):
+        tol = 1e-4 * max(1.0, float(dW1.abs().max()))  # different K splits: fp32 summation order differs
+        assert float((dW - dW1).abs().max()) <= tol, f"problem {i}"
+        if db is not None:
+            assert float((db - db1).abs().max()) <= 1e-4 * max(1.0, float(db1.abs().max())), f"problem {i} bias"

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(WsGeo<NCT>::THREADS, 2) void conv_ws_kernel(const C
       bf16x8 tq;
 #pragma unroll
       for (int r = 0; r < 8; ++r) tq[r] = (bf16)v[r];
-      *reinterpret_cast<bf16x8*>(out + opix * (int)a.out_ps + c8 * 8) = tq;
+      __builtin_nontemporal_store(tq, reinterpret_cast<bf16x8*>(out + opix * (int)a.out_ps + c8 * 8));
     }
   }
   ws_stamp(a, wave, 31);

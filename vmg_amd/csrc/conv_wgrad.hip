@@ -448,17 +448,24 @@ extern "C" int vmg_conv_wgrad_batched(int dtype, int ks, int npairs, const void*
 namespace {
 
 
+constexpr int W3_MAX_PROBS = 8;  // weight-gradient problems of one shape served by one launch (vmg_conv_wgrad3_multi)
 struct Wgrad2K {
-  const char* x[WG_MAX_PAIRS];
-  const char* dy[WG_MAX_PAIRS];
-  int npairs;
-  long long Upair, U;
+  const char* x[W3_MAX_PROBS * WG_MAX_PAIRS];   // [problem][pair]
+  const char* dy[W3_MAX_PROBS * WG_MAX_PAIRS];
+  int npairs, nprob;
+  long long Upair, U;  // K units per pair / per problem
   long long x_ps, dy_ps;
   int Cin, Cout;
-  float* slab;       // [S][ciblk][coblk][8 waves][36 tiles][64][4]
+  float* slab;       // [problem][S][ciblk][coblk][8 waves][36 tiles][64][4]
   int N, H, W, SEG, S;
   int has_bias;
-  int gx, gy;        // co / ci blocks (the grid is 1-D: gx * gy * S workgroups, see xcd_slab_block)
+  int gx, gy;        // co / ci blocks (the grid is 1-D: gx * gy * S * nprob workgroups, see xcd_slab_block)
+  int dbg;           // diagnostics build only (env VMG_WGRAD_DBG): 1 no copies after the prologue, 2 no MFMAs, 4 no fragment reads
+};
+struct Wgrad3Out {   // per problem: where the reduce kernel adds the sums
+  float* dW[W3_MAX_PROBS];
+  float* db[W3_MAX_PROBS];
+  float scale[W3_MAX_PROBS];
 };
 
 constexpr int W2_WAVES = 9, W2_THREADS = 576;  // the 1x1 kernel's workgroup
@@ -518,7 +525,12 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave >> 2, q = wave & 3;
-  const SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S);
+  SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S * a.nprob);
+  const int prob = blk.z / a.S;  // several problems of one shape share the launch: fewer, longer K slabs per problem at a full chip
+  const int zz = blk.z;          // slab index over all problems (the slab workspace is [problem][S]...)
+  blk.z -= prob * a.S;
+  const char* const* xs = a.x + prob * WG_MAX_PAIRS;
+  const char* const* dys = a.dy + prob * WG_MAX_PAIRS;
   const int ob = blk.x * W2_DYC, ib = blk.y * W2_XC;
   const long long u_lo = a.U * blk.z / a.S, u_hi = a.U * (blk.z + 1) / a.S;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
@@ -565,8 +577,8 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   auto issue = [&](int buf) {
     const int x0 = iseg * 32;
     const long long row = ((long long)in_ * a.H + iy) * a.W + x0;
-    const char* dyrow = a.dy[ipair] + row * a.dy_ps * 2;
-    const char* xrow = a.x[ipair] + row * a.x_ps * 2;
+    const char* dyrow = dys[ipair] + row * a.dy_ps * 2;
+    const char* xrow = xs[ipair] + row * a.x_ps * 2;
     char* dst = smem + buf * W3_BUF;
 #pragma unroll
     for (int sl = 0; sl < W3_SLOTS; ++sl) {
@@ -640,12 +652,28 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
     const int su = sn == 0 ? 5 : sn - 1;  // slot of unit j
     const char* src = smem + (has_next ? sn : su) * W3_BUF;  // (last unit: re-read its own slot; the values are not used)
     bf16x8 an[5];
+#ifdef VMG_DIAG
+    if (a.dbg & 4) {
 #pragma unroll
-    for (int c = 0; c < 5; ++c) an[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);
+      for (int c = 0; c < 5; ++c) an[c] = af[c];
+    } else
+#endif
+    {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) an[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);
+    }
 #pragma unroll
     for (int jj = 0; jj < 7; ++jj) {
+#ifdef VMG_DIAG
+      if (!(a.dbg & 2))
+#endif
+      {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) acc[c][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[jj], acc[c][jj], 0, 0, 0);
+        for (int c = 0; c < 5; ++c) acc[c][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[jj], acc[c][jj], 0, 0, 0);
+      }
+#ifdef VMG_DIAG
+      if (!(a.dbg & 4))
+#endif
       bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
     }
     if (a.has_bias && q == 0 && blk.y == 0) {
@@ -654,8 +682,13 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
     }
     if ((j & 1) == 0) {  // behind the MFMAs: units j+5, j+6 -> the slots of units j-1 and j (free since this iteration's barrier)
       const int s5 = su == 0 ? 5 : su - 1;
-      if (j + 5 < nun) issue(s5);
-      if (j + 6 < nun) issue(su);
+#ifdef VMG_DIAG
+      if (!(a.dbg & 1))
+#endif
+      {
+        if (j + 5 < nun) issue(s5);
+        if (j + 6 < nun) issue(su);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) af[c] = an[c];
@@ -663,7 +696,7 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
-  float* sl = a.slab + ((((long long)blk.z * a.gy + blk.y) * a.gx + blk.x) * W3_WAVES + wave) * (W3_TILES * 256);
+  float* sl = a.slab + ((((long long)zz * a.gy + blk.y) * a.gx + blk.x) * W3_WAVES + wave) * (W3_TILES * 256);
 #pragma unroll
   for (int c = 0; c < 5; ++c)
 #pragma unroll
@@ -676,11 +709,14 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   }
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
-                                                                 float* __restrict__ dW, int I_total, int o0, int i0,
-                                                                 float* __restrict__ db, float scale) {
+__global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __restrict__ slab0, int S, int gx, int gy, int Cin, int Cout,
+                                                                 const Wgrad3Out outs, int I_total, int o0, int i0) {
   __shared__ float red[256];
   const long long per_s = (long long)gy * gx * W3_WG_FLOATS;
+  const float* __restrict__ slab = slab0 + (long long)blockIdx.y * S * per_s;  // blockIdx.y = problem
+  float* __restrict__ dW = outs.dW[blockIdx.y];
+  float* __restrict__ db = outs.db[blockIdx.y];
+  const float scale = outs.scale[blockIdx.y];
   for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
     const long long i = e0 + (threadIdx.x & 63);
     const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
@@ -1060,6 +1096,56 @@ int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, 
 
 }  // namespace
 
+// Shared by the single and the multi-problem entry points.  Returns 1 when the workspace cannot hold the slabs (caller falls back).
+static int launch_wgrad3(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin, int64_t dy_ps,
+                         int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws, int64_t ws_bytes,
+                         void* stream) {
+  const int cin8 = (Cin + 7) & ~7, cout8 = (Cout + 7) & ~7;
+  Wgrad2K k;
+  memset(&k, 0, sizeof(k));
+  Wgrad3Out outs;
+  memset(&outs, 0, sizeof(outs));
+  bool any_bias = false;
+  for (int q = 0; q < nprob; ++q) {
+    for (int p = 0; p < npairs; ++p) {
+      k.x[q * WG_MAX_PAIRS + p] = (const char*)x[q * npairs + p];
+      k.dy[q * WG_MAX_PAIRS + p] = (const char*)dy[q * npairs + p];
+    }
+    outs.dW[q] = dW[q];
+    outs.db[q] = db ? db[q] : nullptr;
+    outs.scale[q] = scales[q];
+    any_bias = any_bias || outs.db[q] != nullptr;
+  }
+  k.npairs = npairs; k.nprob = nprob; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = cin8; k.Cout = cout8;  // bounds of the 8-channel vector loads; the reduce kernel keeps the true counts
+  k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32);
+  k.Upair = (long long)N * H * k.SEG; k.U = k.Upair * npairs;
+  k.has_bias = any_bias;
+  const int gx = cdiv(Cout, W2_DYC), gy = cdiv(Cin, W2_XC);
+  long long S = 256 / ((long long)gx * gy * nprob);  // one workgroup per CU over all problems
+  if (S > k.U / 8) S = k.U / 8;
+  if (S < 1) S = 1;
+  const long long need = (long long)nprob * S * gx * gy * W3_WG_FLOATS * 4;
+  if (need > ws_bytes) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  k.S = (int)S; k.slab = (float*)ws; k.gx = gx; k.gy = gy;
+#ifdef VMG_DIAG
+  { const char* e = getenv("VMG_WGRAD_DBG"); k.dbg = e ? atoi(e) : 0; }
+#endif
+  static bool attr3[VMG_MAX_DEVICES] = {};  // the attribute is per device
+  const int dev3 = vmg_current_device();
+  if (!attr3[dev3]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr3[dev3] = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)(gx * gy * S * nprob)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
+  VMG_LAUNCH_CHECK();
+  const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
+  const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
+  hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3, nprob), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, outs, I_total, o0, i0);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W3_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~94 MB)
 
 extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
@@ -1126,32 +1212,27 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   for (int p = 0; ok && p < npairs; ++p) ok = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
   if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream, (float*)ws, ws_bytes);
   VMG_CHECK(N > 0 && H > 0 && W > 0 && dW && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad arguments");
-  Wgrad2K k;
-  memset(&k, 0, sizeof(k));
-  for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
-  k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = cin8; k.Cout = cout8;  // bounds of the 8-channel vector loads; the reduce kernel keeps the true counts
-  k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32);
-  k.Upair = (long long)N * H * k.SEG; k.U = k.Upair * npairs;
-  k.has_bias = db != nullptr;
-  const int gx = cdiv(Cout, W2_DYC), gy = cdiv(Cin, W2_XC);
-  long long S = 256 / ((long long)gx * gy);
-  if (S > k.U / 8) S = k.U / 8;
-  if (S < 1) S = 1;
-  const long long need = S * gx * gy * W3_WG_FLOATS * 4;
-  if (need > ws_bytes) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
-  hipStream_t st = (hipStream_t)stream;
-  k.S = (int)S; k.slab = (float*)ws; k.gx = gx; k.gy = gy;
-  static bool attr3[VMG_MAX_DEVICES] = {};  // the attribute is per device
-  const int dev3 = vmg_current_device();
-  if (!attr3[dev3]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr3[dev3] = true;
-  }
-  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)(gx * gy * S)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
-  VMG_LAUNCH_CHECK();
-  const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
-  const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
-  hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
-  VMG_LAUNCH_CHECK();
-  return 0;
+  const int rc = launch_wgrad3(1, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, &dW, I_total, o0, i0, &db, &scale, ws, ws_bytes, stream);
+  if (rc == 1) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream);
+  return rc;
+}
+
+// Several weight gradients of ONE shape (the 30 equal convs of a recurrent residual chain all complete at the same moment of the
+// backward pass) in one launch: x / dy hold nprob * npairs pointers [problem][pair], dW / db one pointer per problem.  With one problem per
+// launch every conv cuts its pixels into ~85 K slabs to fill the chip and writes 85 x 864 KB of partial sums that a second kernel reads
+// back (40 us of a 100 us gradient); with 8 problems per launch a problem needs only ~10 slabs.
+extern "C" int vmg_conv_wgrad3_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin,
+                                     int64_t dy_ps, int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales,
+                                     void* ws, int64_t ws_bytes, void* stream) {
+  VMG_CHECK(nprob >= 1 && nprob <= W3_MAX_PROBS && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && ws && scales, "conv_wgrad3_multi: 1..%d problems, 1..%d pairs",
+            W3_MAX_PROBS, WG_MAX_PAIRS);
+  const int cin8 = (Cin + 7) & ~7, cout8 = (Cout + 7) & ~7;
+  VMG_CHECK(N > 0 && H > 0 && W > 0 && (x_ps % 8 == 0) && (dy_ps % 8 == 0) && x_ps >= cin8 && dy_ps >= cout8 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0,
+            "conv_wgrad3_multi: bf16 3x3 with 8-channel vectors only");
+  for (int p = 0; p < nprob * npairs; ++p)
+    VMG_CHECK(x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0), "conv_wgrad3_multi: null or unaligned pointer %d", p);
+  for (int p = 0; p < nprob; ++p) VMG_CHECK(dW[p], "conv_wgrad3_multi: null gradient pointer %d", p);
+  const int rc = launch_wgrad3(nprob, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scales, ws, ws_bytes, stream);
+  VMG_CHECK(rc != 1, "conv_wgrad3_multi: the workspace is too small");
+  return rc;
 }

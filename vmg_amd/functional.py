@@ -163,6 +163,8 @@ class _DeferredWgrad:
         self.callbacks = []  # called with each parameter whose .grad has just been completed
         self.managed = set()  # ids of the parameters (weights and their biases) whose gradient is completed HERE, not by autograd
         self._queued = False
+        self.ready = []     # [weight, bias, entries] whose last use has been seen: launched by drain()
+        self.hold = 0       # > 0: a node that completes many parameters at once (a residual chain) is collecting them
 
     def begin_forward(self):
         """New top-level forward pass: a fresh generation; counts of passes older than KEEP_GENERATIONS are dropped."""
@@ -227,22 +229,60 @@ class _DeferredWgrad:
         self._queued = False
         for key in list(self.pending):
             self.flush(self.pending[key][0])
+        self.hold = 0
+        self.drain()
 
     def flush(self, weight):
         ent = self.pending.pop(id(weight), None)
         if ent is None:
             return
-        weight, bias, entries = ent
-        if weight.grad is None:
-            weight.grad = torch.zeros_like(weight, dtype=torch.float32)
-        if bias is not None and bias.requires_grad and bias.grad is None:
-            bias.grad = torch.zeros_like(bias, dtype=torch.float32)
-        db = bias.grad if (bias is not None and bias.requires_grad) else None
-        _wgrad_entries(entries, weight.grad, db)
-        for cb in self.callbacks:
-            cb(weight)
-            if db is not None:
-                cb(bias)
+        self.ready.append(ent)
+        if not self.hold:
+            self.drain()
+
+    @staticmethod
+    def _multi_sig(ent):
+        """Signature under which complete parameters can share one vmg_conv_wgrad3_multi launch, or None."""
+        weight, _, entries = ent
+        e0 = entries[0]
+        if len(e0[1]) != 1 or e0[3] != 3 or weight.dim() != 4 or weight.shape[1] != e0[1][0]:
+            return None
+        x0, d0 = e0[0][0], e0[2]
+        if x0.shape[-1] != e0[1][0] or not K.conv_wgrad3_multi_ok(x0, d0, 3):
+            return None
+        for e in entries:
+            x, d = e[0][0], e[2]
+            if e[1] != e0[1] or e[3:7] != e0[3:7] or e[7] != e0[7] or x.shape != x0.shape or d.shape != d0.shape or x.stride() != x0.stride() or \
+                    d.stride() != d0.stride() or not K.conv_wgrad3_multi_ok(x, d, 3):
+                return None
+        return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(x0.stride()), tuple(d0.stride()))
+
+    def drain(self):
+        """Launch the gradients of every complete parameter: parameters of one shape share launches (eight per launch)."""
+        if not self.ready:
+            return
+        ready, self.ready = self.ready, []
+        groups = {}
+        for ent in ready:
+            weight, bias = ent[0], ent[1]
+            if weight.grad is None:
+                weight.grad = torch.zeros_like(weight, dtype=torch.float32)
+            if bias is not None and bias.requires_grad and bias.grad is None:
+                bias.grad = torch.zeros_like(bias, dtype=torch.float32)
+            groups.setdefault(self._multi_sig(ent), []).append(ent)
+        for sig, ents in groups.items():
+            if sig is None or len(ents) < 2:
+                for weight, bias, entries in ents:
+                    _wgrad_entries(entries, weight.grad, bias.grad if (bias is not None and bias.requires_grad) else None)
+            else:
+                probs = [([e[0][0] for e in entries], [e[2] for e in entries], weight.grad,
+                          bias.grad if (bias is not None and bias.requires_grad) else None, entries[0][7]) for weight, bias, entries in ents]
+                K.conv_wgrad3_multi(probs, sig[3], sig[4], sig[5])
+        for weight, bias, _ in ready:
+            for cb in self.callbacks:
+                cb(weight)
+                if bias is not None and bias.requires_grad:
+                    cb(bias)
 
     def flush_all(self):
         self._end_of_backward()
@@ -426,6 +466,8 @@ class _ResidualChain(torch.autograd.Function):
         pd1 = [packed(params[2 + 4 * k], dt, "dgrad", None, 0, C, tiles=tiles, deep=deep) for k in range(nblk)]
         pd2 = [packed(params[4 + 4 * k], dt, "dgrad", None, 0, C, tiles=tiles, deep=deep) for k in range(nblk)]
         gys, gts = K.resblock_chain_backward(g, ts, pd1, pd2, r, deep)
+        if ctx.defer:
+            DEFERRED.hold += 1  # the chain's parameters complete together: their gradients share launches (drained below)
         for k in range(nblk - 1, -1, -1):
             w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
             if ctx.defer:
@@ -449,6 +491,9 @@ class _ResidualChain(torch.autograd.Function):
             off += c
         if ctx.defer:
             DEFERRED.add(w0, b0, srcs, src_ch, dpre0, 3, N, H, W, gen=ctx.gen)
+            DEFERRED.hold -= 1
+            if not DEFERRED.hold:
+                DEFERRED.drain()
         elif ctx.wgrad:
             pg[0], pg[1] = _wgrad_now(w0, True, srcs, src_ch, dpre0, 3, N, H, W)
         return (None, None, *d_srcs, *pg)

@@ -565,6 +565,46 @@ def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], 
                                               hip.stream_ptr()), "vmg_conv_wgrad_batched_ws")
 
 
+def conv_wgrad3_multi_ok(x: torch.Tensor, dy: torch.Tensor, ks: int) -> bool:
+    """Shapes vmg_conv_wgrad3_multi takes: bf16, 3x3, pixel strides that are multiples of 8 channels, 16-byte aligned tensors."""
+    return (ks == 3 and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.stride(-1) == 1 and dy.stride(-1) == 1 and
+            x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+
+
+def conv_wgrad3_multi(probs, N: int, H: int, W: int):
+    """probs: list of (xs, dys, dW, db, scale) of ONE shape (same channel counts, strides and number of pairs): dW_i += scale_i * sum_p
+    wgrad(xs_i[p], dys_i[p]), eight problems per launch."""
+    xs0, dys0, dW0 = probs[0][:3]
+    npairs = len(xs0)
+    Cin, Cout = xs0[0].shape[-1], dys0[0].shape[-1]
+    xps, dps = _pix_stride(xs0[0]), _pix_stride(dys0[0])
+    I_total = dW0.shape[1]
+    M = N * H * W
+    for xs, dys, dW, db, _ in probs:
+        hip.require_cuda(dW, db, *xs, *dys)
+        if len(xs) != npairs or len(dys) != npairs or dW.shape != dW0.shape or dW.dtype != torch.float32 or not dW.is_contiguous() or \
+                (db is not None and (db.dtype != torch.float32 or not db.is_contiguous() or db.numel() != dW.shape[0])):
+            raise HipError("conv_wgrad3_multi: problems must share the shape; gradients contiguous fp32")
+        for x, d in zip(xs, dys):
+            if x.dtype != torch.bfloat16 or d.dtype != torch.bfloat16 or x.shape[-1] != Cin or d.shape[-1] != Cout or x.numel() // Cin != M or \
+                    d.numel() // Cout != M or _pix_stride(x) != xps or _pix_stride(d) != dps:
+                raise HipError("conv_wgrad3_multi: all pairs must share shape, dtype and strides")
+    if dW0.shape[0] != Cout or dW0.dim() != 4 or dW0.shape[2] != 3 or Cin > I_total:
+        raise HipError("conv_wgrad3_multi: gradient tensor does not match the convolution")
+    l = hip.lib()
+    ws = _wgrad_workspace(dW0.device)
+    for s in range(0, len(probs), 8):
+        grp = probs[s:s + 8]
+        n = len(grp)
+        xa = (ctypes.c_void_p * (n * npairs))(*[t.data_ptr() for g in grp for t in g[0]])
+        da = (ctypes.c_void_p * (n * npairs))(*[t.data_ptr() for g in grp for t in g[1]])
+        wa = (ctypes.c_void_p * n)(*[g[2].data_ptr() for g in grp])
+        ba = (ctypes.c_void_p * n)(*[(g[3].data_ptr() if g[3] is not None else None) for g in grp])
+        sa = (ctypes.c_float * n)(*[float(g[4]) for g in grp])
+        hip.check(l.vmg_conv_wgrad3_multi(n, npairs, xa, da, N, H, W, xps, Cin, dps, Cout, wa, I_total, 0, 0, ba, sa, ws.data_ptr(), ws.numel(),
+                                          hip.stream_ptr()), "vmg_conv_wgrad3_multi")
+
+
 _WGRAD_WS = {}
 
 
