@@ -24,6 +24,18 @@ namespace {
 constexpr int WG_MAX_PAIRS = 16;  // (x, dy) pairs summed by one launch (uses of a shared weight)
 __device__ __attribute__((aligned(256))) unsigned int g_zero_buf[64];  // 256 zero bytes: load / DMA source for out-of-image lanes
 
+// LDS-DMA (1 KiB per wave: 16 bytes per lane from a per-lane global address into a lane-linear LDS block) as an asm statement: when a
+// wave issues the BUILTIN, hipcc treats every later ds_read of that wave as possibly aliasing the copy and puts s_waitcnt vmcnt(0) in
+// front of it -- the copies in flight (the whole prefetch ring) are then waited for before every fragment read, and copies and MFMAs
+// run one after the other (measured on the 3x3 kernel: copies alone 39 us, MFMAs + reads 52 us, together 89 us).  Hidden in asm the
+// copies are counted by hand (the s_waitcnt vmcnt(N) before the barriers); M0 is saved and restored inside the statement.
+__device__ __forceinline__ void glds16_hidden(const char* gsrc, char* lds_dst) {
+  unsigned keep;
+  const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));  // (wave-uniform by construction)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+}
+
 // The gx * gy workgroups of one K slab stream the SAME dY / X lines.  The hardware hands workgroup L of a 1-D grid to XCD L % 8 (each XCD
 // has its own L2), so the logical index is permuted: the blocks of a slab are consecutive on ONE XCD, run at the same time and
 // share the lines through that L2 instead of fetching them gx * gy times from HBM.
@@ -547,23 +559,23 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
   // ---- lane constants of the three copy instructions: vector L of the [dY | X] list
-  int s_off[W3_SLOTS], s_a[W3_SLOTS], s_b[W3_SLOTS], s_kind[W3_SLOTS];  // kind 0 dY (a = pixel), 1 X (a = row, b = column), 2 padding
+  // (a, b, kind packed into one register per slot: the kernel sits at its 256-register budget, and a spilled lane constant is reloaded with
+  //  s_waitcnt vmcnt(0) -- which also waits for every copy in flight and serialises the copies with the MFMAs)
+  int s_off[W3_SLOTS], s_abk[W3_SLOTS];  // abk = a | b << 8 | kind << 16;  kind 0 dY (a = pixel), 1 X (a = row, b = column), 2 padding
 #pragma unroll
   for (int sl = 0; sl < W3_SLOTS; ++sl) {
     const int L = (sl * W3_WAVES + wave) * 64 + lane;
     if (L < W3_DYV) {
       const int pp = L / 18, v = L - pp * 18;
-      s_kind[sl] = (ob + v * 8 + 8 <= a.Cout) ? 0 : 2;
-      s_a[sl] = pp; s_b[sl] = 0;
+      s_abk[sl] = pp | (((ob + v * 8 + 8 <= a.Cout) ? 0 : 2) << 16);
       s_off[sl] = (int)((pp * a.dy_ps + ob + v * 8) * 2);
     } else if (L < W3_VECS) {
       const int vec = L - W3_DYV, pp = vec / 6, v = vec - pp * 6;
       const int rr = pp / W2_XW, col = pp - rr * W2_XW;
-      s_kind[sl] = (ib + v * 8 + 8 <= a.Cin) ? 1 : 2;
-      s_a[sl] = rr; s_b[sl] = col;
+      s_abk[sl] = rr | (col << 8) | (((ib + v * 8 + 8 <= a.Cin) ? 1 : 2) << 16);
       s_off[sl] = (int)((((long long)(rr - 1) * a.W + (col - 1)) * a.x_ps + ib + v * 8) * 2);
     } else {
-      s_kind[sl] = 2; s_a[sl] = 0; s_b[sl] = 0; s_off[sl] = 0;
+      s_abk[sl] = 2 << 16; s_off[sl] = 0;
     }
   }
   int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
@@ -584,15 +596,16 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
     for (int sl = 0; sl < W3_SLOTS; ++sl) {
       bool ok;
       const char* src;
-      if (s_kind[sl] == 0) {
-        ok = x0 + s_a[sl] < a.W;
+      const int kind = s_abk[sl] >> 16, sa = s_abk[sl] & 255, sb = (s_abk[sl] >> 8) & 255;
+      if (kind == 0) {
+        ok = x0 + sa < a.W;
         src = dyrow + s_off[sl];
       } else {
-        const int yy = iy + s_a[sl] - 1, xx = x0 + s_b[sl] - 1;
-        ok = s_kind[sl] == 1 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const int yy = iy + sa - 1, xx = x0 + sb - 1;
+        ok = kind == 1 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
         src = xrow + s_off[sl];
       }
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ok ? src : zsrc), LDS_PTR(dst + (sl * W3_WAVES + wave) * 1024), 16, 0, 0);
+      glds16_hidden(ok ? src : zsrc, dst + (sl * W3_WAVES + wave) * 1024);
     }
     if (++iseg == a.SEG) {
       iseg = 0;
@@ -802,9 +815,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
     const bool pok = ipix + p_l < a.Mpair;
     char* dyt = smem + buf * L2_BUF;
     const char* s0 = (pok && c_dy) ? a.dy[ipair] + ipix * a.dy_ps * 2 + off_dy : zsrc;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(s0), LDS_PTR(dyt + wave * 1024), 16, 0, 0);
+    glds16_hidden(s0, dyt + wave * 1024);
     const char* s1 = (pok && c_x) ? a.x[ipair] + ipix * a.x_ps * 2 + off_x : zsrc;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(s1), LDS_PTR(dyt + L2_TILE_BYTES + wave * 1024), 16, 0, 0);
+    glds16_hidden(s1, dyt + L2_TILE_BYTES + wave * 1024);
     ipix += 32;
     if (ipix >= a.Mpair) { ipix = 0; ++ipair; }
   };
