@@ -107,7 +107,9 @@ __device__ __forceinline__ long long ln_src_elem(const LnMap& m, long long row, 
   return ((n * (m.H >> 1) + (y >> 1)) * (m.W >> 1) + (x >> 1)) * (4LL * m.Cseg) + sg * m.Cseg + c;
 }
 
-template <typename T, int V, int G>
+// NV = vectors per lane (1, 2 or 4): the register arrays are exactly as long as the row needs, the affine weights of a lane's channels
+// are loaded once, and the next row's vectors are fetched before the current row's reductions (one row of loads always in flight).
+template <typename T, int V, int G, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, long long M,
@@ -115,14 +117,35 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
-  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += (long long)gridDim.x * groups_per_block) {
-    VecN<T, V> buf[LN_MAXV];
+  const long long stride = (long long)gridDim.x * groups_per_block;
+  float wr[NV][V], br[NV][V];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = (gl + k * G) * V + e;
+      wr[k][e] = c < C ? w[c] : 0.f;
+      br[k][e] = c < C ? b[c] : 0.f;
+    }
+  long long row = blockIdx.x * groups_per_block + threadIdx.x / G;
+  VecN<T, V> nxt[NV];
+  auto fetch = [&](long long r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int vi = gl + k * G;
+      if (vi < nvec) nxt[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, r, vi * V, C));
+    }
+  };
+  if (row < M) fetch(row);
+  for (; row < M; row += stride) {
+    VecN<T, V> buf[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) buf[k] = nxt[k];
+    if (row + stride < M) fetch(row + stride);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) {
-        buf[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, row, vi * V, C));
+    for (int k = 0; k < NV; ++k) {
+      if (gl + k * G < nvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) s += to_f32(buf[k].v[e]);
       }
@@ -130,9 +153,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float mu = group_sum<G>(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) {
+    for (int k = 0; k < NV; ++k) {
+      if (gl + k * G < nvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const float d = to_f32(buf[k].v[e]) - mu;
@@ -147,22 +169,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
     T* yr = y + row * C;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int vi = gl + k * G;
       if (vi < nvec) {
         VecN<T, V> o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const int c = vi * V + e;
-          o.v[e] = from_f32<T>((to_f32(buf[k].v[e]) - mu) * rs * w[c] + b[c]);
-        }
+        for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>((to_f32(buf[k].v[e]) - mu) * rs * wr[k][e] + br[k][e]);
         reinterpret_cast<VecN<T, V>*>(yr)[vi] = o;
       }
     }
   }
 }
 
-template <typename T, int V, int G>
+template <typename T, int V, int G, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
@@ -171,27 +190,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
-  float pdw[LN_MAXV][V], pdb[LN_MAXV][V];
+  const long long stride = (long long)gridDim.x * groups_per_block;
+  float pdw[NV][V], pdb[NV][V], wr[NV][V];
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k)
+  for (int k = 0; k < NV; ++k)
 #pragma unroll
-    for (int e = 0; e < V; ++e) pdw[k][e] = pdb[k][e] = 0.f;
-  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += (long long)gridDim.x * groups_per_block) {
-    const float mu = mean[row], rs = rstd[row];
-    VecN<T, V> bx[LN_MAXV], bg[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dy * w
+    for (int e = 0; e < V; ++e) {
+      pdw[k][e] = pdb[k][e] = 0.f;
+      const int c = (gl + k * G) * V + e;
+      wr[k][e] = c < C ? w[c] : 0.f;
+    }
+  long long row = blockIdx.x * groups_per_block + threadIdx.x / G;
+  VecN<T, V> nx[NV], ng[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](long long r) __attribute__((always_inline)) {
+    nmu = mean[r];
+    nrs = rstd[r];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int vi = gl + k * G;
       if (vi < nvec) {
-        bx[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, row, vi * V, C));
-        bg[k] = reinterpret_cast<const VecN<T, V>*>(dy + row * C)[vi];
+        nx[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, r, vi * V, C));
+        ng[k] = reinterpret_cast<const VecN<T, V>*>(dy + r * C)[vi];
+      }
+    }
+  };
+  if (row < M) fetch(row);
+  for (; row < M; row += stride) {
+    const float mu = nmu, rs = nrs;
+    VecN<T, V> bx[NV], bg[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { bx[k] = nx[k]; bg[k] = ng[k]; }
+    if (row + stride < M) fetch(row + stride);  // the next row's loads fly while this row is reduced and written
+    float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dy * w
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (gl + k * G < nvec) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const int c = vi * V + e;
           const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
           const float d = to_f32(bg[k].v[e]);
-          const float g = d * w[c];
+          const float g = d * wr[k][e];
           s1 += g;
           s2 += g * xh;
           pdw[k][e] += d * xh;
@@ -202,15 +241,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     s1 = group_sum<G>(s1) / C;
     s2 = group_sum<G>(s2) / C;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int vi = gl + k * G;
       if (vi < nvec) {
         VecN<T, V> o;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const int c = vi * V + e;
           const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
-          const float g = to_f32(bg[k].v[e]) * w[c];
+          const float g = to_f32(bg[k].v[e]) * wr[k][e];
           o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
         }
         *reinterpret_cast<VecN<T, V>*>(dx + ln_src_elem(map, row, vi * V, C)) = o;
@@ -222,7 +260,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const int vi = gl + k * G;
     if (vi < nvec) {
 #pragma unroll
@@ -239,7 +277,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-int ln_group(int nvec) { return nvec <= 16 ? 16 : (nvec <= 32 ? 32 : 64); }
+// lanes per row: the G in {16, 32, 64} that wastes the fewest lane slots (G * ceil(nvec / G)), the smaller G on a tie -- more rows per
+// block and more vectors (= loads in flight) per lane: C = 144 bf16 (18 vectors) runs on 16 lanes x 2 vectors, not 32 x 1
+int ln_group(int nvec) {
+  int best = 64, slots = 1 << 30;
+  for (int g = 64; g >= 16; g >>= 1) {
+    const int nv = (nvec + g - 1) / g;
+    if (nv > LN_MAXV) continue;
+    const int nvp = nv == 3 ? 4 : nv;  // (instantiated: 1, 2, 4 vectors per lane)
+    if (g * nvp <= slots) { slots = g * nvp; best = g; }
+  }
+  return best;
+}
 
 }  // namespace
 
@@ -283,11 +332,14 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
-  const int blocks = (int)(cdiv64(M, rows_per_block) > 8192 ? 8192 : cdiv64(M, rows_per_block));
-#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps, map)
-  if (G == 16) LN_LAUNCH(16);
-  else if (G == 32) LN_LAUNCH(32);
-  else LN_LAUNCH(64);
+  const int blocks = (int)(cdiv64(M, rows_per_block * 4) > 1536 ? 1536 : cdiv64(M, rows_per_block * 4));  // several rows per lane group: the hoisted affine weights and the prefetch pay
+  const int nv = (nvec + G - 1) / G;
+#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps, map)
+#define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
+  if (G == 16) LN_LAUNCH_G(16);
+  else if (G == 32) LN_LAUNCH_G(32);
+  else LN_LAUNCH_G(64);
+#undef LN_LAUNCH_G
 #undef LN_LAUNCH
   VMG_LAUNCH_CHECK();
   return 0;
@@ -300,12 +352,15 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
-  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 1024 ? 1024 : cdiv64(M, rows_per_block * 8));
+  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 256 ? 256 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
   const int lds = 2 * C * 4;
-#define LN_LAUNCH(GG) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map)
-  if (G == 16) LN_LAUNCH(16);
-  else if (G == 32) LN_LAUNCH(32);
-  else LN_LAUNCH(64);
+  const int nv = (nvec + G - 1) / G;
+#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map)
+#define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
+  if (G == 16) LN_LAUNCH_G(16);
+  else if (G == 32) LN_LAUNCH_G(32);
+  else LN_LAUNCH_G(64);
+#undef LN_LAUNCH_G
 #undef LN_LAUNCH
   VMG_LAUNCH_CHECK();
   return 0;
