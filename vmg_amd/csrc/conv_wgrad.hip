@@ -16,6 +16,7 @@
 // flight while the current one is multiplied).  At the end the 4 waves' accumulators are summed with LDS float
 // atomics into a [co][ci][tap] image = the OIHW order, and written out with coalesced global float atomics.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -558,26 +559,17 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   const bf16 one = (bf16)1.0f;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
-  // ---- lane constants of the three copy instructions: vector L of the [dY | X] list
-  // (a, b, kind packed into one register per slot: the kernel sits at its 256-register budget, and a spilled lane constant is reloaded with
-  //  s_waitcnt vmcnt(0) -- which also waits for every copy in flight and serialises the copies with the MFMAs)
-  int s_off[W3_SLOTS], s_abk[W3_SLOTS];  // abk = a | b << 8 | kind << 16;  kind 0 dY (a = pixel), 1 X (a = row, b = column), 2 padding
-#pragma unroll
-  for (int sl = 0; sl < W3_SLOTS; ++sl) {
-    const int L = (sl * W3_WAVES + wave) * 64 + lane;
-    if (L < W3_DYV) {
-      const int pp = L / 18, v = L - pp * 18;
-      s_abk[sl] = pp | (((ob + v * 8 + 8 <= a.Cout) ? 0 : 2) << 16);
-      s_off[sl] = (int)((pp * a.dy_ps + ob + v * 8) * 2);
-    } else if (L < W3_VECS) {
-      const int vec = L - W3_DYV, pp = vec / 6, v = vec - pp * 6;
-      const int rr = pp / W2_XW, col = pp - rr * W2_XW;
-      s_abk[sl] = rr | (col << 8) | (((ib + v * 8 + 8 <= a.Cin) ? 1 : 2) << 16);
-      s_off[sl] = (int)((((long long)(rr - 1) * a.W + (col - 1)) * a.x_ps + ib + v * 8) * 2);
-    } else {
-      s_abk[sl] = 2 << 16; s_off[sl] = 0;
-    }
-  }
+  // ---- copy instructions.  The kernel is bound by INSTRUCTION ISSUE, not by memory (with every copy an L2 hit it runs at the same
+  // speed) nor by the matrix pipe: per 32-pixel unit a wave has 35 MFMAs (560 cycles) and, in the first version, ~450 other instructions
+  // (per-lane 64-bit address arithmetic of the copies, 64-bit loop counters, slot rotation, fragment double buffers): 0.44 us of loop
+  // skeleton + 0.57 us of copy issue + 0.5 us of MFMAs per unit.  Hence: a lane keeps a 64-bit POINTER per copy instruction and adds a
+  // wave-uniform delta per unit; the loop is unrolled over the six LDS slots (static slot addresses, static barrier parity, 32-bit
+  // counters); one fragment set, re-read behind the last MFMA that uses it.
+  // Lane constants of the three copy instructions: vector L of the [dY | X] list.  Chunk sl * 8 + wave < 9 is a dY chunk, the rest X
+  // (wave-uniform); abk = a | b << 8 | kind << 16, kind 0 dY (a = pixel), 1 X (a = row, b = column), 2 padding (reads the zero buffer).
+  int s_abk[W3_SLOTS];
+  const char* s_ptr[W3_SLOTS];  // source of the NEXT unit to be issued
+  const int nun = (int)(u_hi - u_lo);
   int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
   {
     const long long uu = u_lo - (long long)ipair * a.Upair;
@@ -586,34 +578,60 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
     iy = (int)(r % a.H);
     in_ = (int)(r / a.H);
   }
-  auto issue = [&](int buf) {
+  {
+    const long long row0 = ((long long)in_ * a.H + iy) * a.W + iseg * 32;
+#pragma unroll
+    for (int sl = 0; sl < W3_SLOTS; ++sl) {
+      const int L = (sl * W3_WAVES + wave) * 64 + lane;
+      if (L < W3_DYV) {
+        const int pp = L / 18, v = L - pp * 18;
+        s_abk[sl] = pp | (((ob + v * 8 + 8 <= a.Cout) ? 0 : 2) << 16);
+        s_ptr[sl] = dys[ipair] + ((row0 + pp) * a.dy_ps + ob + v * 8) * 2;
+      } else if (L < W3_VECS) {
+        const int vec = L - W3_DYV, pp = vec / 6, v = vec - pp * 6;
+        const int rr = pp / W2_XW, col = pp - rr * W2_XW;
+        s_abk[sl] = rr | (col << 8) | (((ib + v * 8 + 8 <= a.Cin) ? 1 : 2) << 16);
+        s_ptr[sl] = xs[ipair] + ((row0 + (long long)(rr - 1) * a.W + (col - 1)) * a.x_ps + ib + v * 8) * 2;
+      } else {
+        s_abk[sl] = 2 << 16;
+        s_ptr[sl] = zsrc;
+      }
+    }
+  }
+  const long long pair_pix = (long long)a.N * a.H * a.W;
+  const int row_adv = a.W - (a.SEG - 1) * 32;  // pixels from the last segment of a row to the start of the next row
+  auto issue = [&](int buf) __attribute__((always_inline)) {
     const int x0 = iseg * 32;
-    const long long row = ((long long)in_ * a.H + iy) * a.W + x0;
-    const char* dyrow = dys[ipair] + row * a.dy_ps * 2;
-    const char* xrow = xs[ipair] + row * a.x_ps * 2;
     char* dst = smem + buf * W3_BUF;
 #pragma unroll
     for (int sl = 0; sl < W3_SLOTS; ++sl) {
+      const int abk = s_abk[sl], kind = abk >> 16, sa = abk & 255, sb = (abk >> 8) & 255;
       bool ok;
-      const char* src;
-      const int kind = s_abk[sl] >> 16, sa = s_abk[sl] & 255, sb = (s_abk[sl] >> 8) & 255;
-      if (kind == 0) {
-        ok = x0 + sa < a.W;
-        src = dyrow + s_off[sl];
-      } else {
-        const int yy = iy + sa - 1, xx = x0 + sb - 1;
-        ok = kind == 1 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        src = xrow + s_off[sl];
-      }
-      glds16_hidden(ok ? src : zsrc, dst + (sl * W3_WAVES + wave) * 1024);
+      if (sl * W3_WAVES + wave < W3_DYV / 64) ok = (kind == 0) & ((unsigned)(x0 + sa) < (unsigned)a.W);
+      else ok = (kind == 1) & ((unsigned)(iy + sa - 1) < (unsigned)a.H) & ((unsigned)(x0 + sb - 1) < (unsigned)a.W);
+      glds16_hidden(ok ? s_ptr[sl] : zsrc, dst + (sl * W3_WAVES + wave) * 1024);
     }
+    // odometer + the wave-uniform pointer deltas to the next unit
+    long long adv = 32;  // pixels
+    long long rebase_dy = 0, rebase_x = 0;
     if (++iseg == a.SEG) {
       iseg = 0;
+      adv = row_adv;
       if (++iy == a.H) {
         iy = 0;
-        if (++in_ == a.N) { in_ = 0; ++ipair; }
+        if (++in_ == a.N) {
+          in_ = 0;
+          if (ipair + 1 < a.npairs) {  // next (x, dy) pair: back to pixel 0 of other tensors
+            rebase_dy = dys[ipair + 1] - dys[ipair] - pair_pix * a.dy_ps * 2;
+            rebase_x = xs[ipair + 1] - xs[ipair] - pair_pix * a.x_ps * 2;
+          }
+          ++ipair;
+        }
       }
     }
+    const long long d_dy = adv * a.dy_ps * 2 + rebase_dy, d_x = adv * a.x_ps * 2 + rebase_x;
+#pragma unroll
+    for (int sl = 0; sl < W3_SLOTS; ++sl) s_ptr[sl] += (sl * W3_WAVES + wave < W3_DYV / 64) ? d_dy : d_x;
   };
 
   // ---- fragment addresses (within a buffer): dY rows are 288 B, X rows 96 B; lane i = 4qq+pp of a 16-lane group supplies
@@ -622,20 +640,19 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   const int a_off = (8 * lg + (li >> 2)) * (W2_DYC * 2) + (h * 5 * 16 + 4 * (li & 3)) * 2;  // + c * 32 for co tile c of this wave
   int b_off[7];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int col = min(q * 7 + j, 26), itile = col / 9, tap = col - 9 * itile, ky = tap / 3, kx = tap - 3 * ky;
-    b_off[j] = W3_DYV * 16 + ky * W2_XW * (W2_XC * 2) + (kx + 8 * lg + (li >> 2)) * (W2_XC * 2) + (itile * 16 + 4 * (li & 3)) * 2;
+  for (int jj = 0; jj < 7; ++jj) {
+    const int col = min(q * 7 + jj, 26), itile = col / 9, tap = col - 9 * itile, ky = tap / 3, kx = tap - 3 * ky;
+    b_off[jj] = W3_DYV * 16 + ky * W2_XW * (W2_XC * 2) + (kx + 8 * lg + (li >> 2)) * (W2_XC * 2) + (itile * 16 + 4 * (li & 3)) * 2;
   }
 
   // SIX unit slots, one barrier per TWO units.  Unit j lives in slot j % 6; iteration j multiplies unit j (fragments already in
   // registers) and reads unit j+1's fragments.  At the barrier of an even j every wave has (a) waited for its share of units
   // j+1 and j+2 (units j+3, j+4 stay in flight: the wait is counted) and (b) drained its reads of unit j; afterwards units
   // j+5 and j+6 are issued into the slots of units j-1 and j.
-  const long long nun = u_hi - u_lo;
   for (int j = 0; j < 5; ++j)
     if (j < nun) issue(j);
   {
-    const long long later = nun > 3 ? (nun > 4 ? 2 : 1) : 0;  // units 3, 4 may stay in flight
+    const int later = nun > 3 ? (nun > 4 ? 2 : 1) : 0;  // units 3, 4 may stay in flight
     if (later == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -647,14 +664,16 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
 #pragma unroll
     for (int c = 0; c < 5; ++c) af[c] = tr_read(smem + a_off + c * 32, W2_DYC * 2);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) bfg[j] = tr_read(smem + b_off[j], W2_XC * 2);
+    for (int jj = 0; jj < 7; ++jj) bfg[jj] = tr_read(smem + b_off[jj], W2_XC * 2);
   }
-  int sn = 1;  // slot of unit j+1
-  for (long long j = 0; j < nun; ++j) {
-    const bool has_next = j + 1 < nun;
-    const bool sync = (j & 1) == 0;  // (j = 0 too: every wave's prologue reads of unit 0 must be done before unit 6 overwrites its slot)
-    if (sync) {
-      const long long later = (j + 3 < nun ? 1 : 0) + (j + 4 < nun ? 1 : 0);
+  const bool do_bias = a.has_bias && q == 0 && blk.y == 0;
+  // one unit; SU = its slot (compile-time), j = its index.  Returns false when the slab is finished.
+  auto unit = [&](int j, auto su_c) __attribute__((always_inline)) -> bool {
+    constexpr int SU = decltype(su_c)::value, SN = (SU + 1) % 6, S5 = (SU + 5) % 6;
+    constexpr bool SYNC = (SU & 1) == 0;  // slots alternate with the unit index: even units synchronise
+    if (j >= nun) return false;
+    if (SYNC) {
+      const int later = (j + 3 < nun ? 1 : 0) + (j + 4 < nun ? 1 : 0);
       if (later == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -662,18 +681,22 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    const int su = sn == 0 ? 5 : sn - 1;  // slot of unit j
-    const char* src = smem + (has_next ? sn : su) * W3_BUF;  // (last unit: re-read its own slot; the values are not used)
-    bf16x8 an[5];
+    const char* src = smem + ((j + 1 < nun) ? SN : SU) * W3_BUF;  // (last unit: re-read its own slot; the values are not used)
+    // units j+5, j+6 -> the slots of units j-1 and j (free since this unit's barrier).  The two waves of a SIMD (h = 0, 1) are kept in
+    // step by the barriers: h = 0 issues its copies BEFORE its MFMAs, h = 1 after them, so that one wave's address arithmetic runs
+    // under the other wave's MFMAs instead of both leaving the matrix pipe idle at the same time.
+    if (SYNC && h == 0) {
 #ifdef VMG_DIAG
-    if (a.dbg & 4) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) an[c] = af[c];
-    } else
+      if (!(a.dbg & 1))
 #endif
-    {
+      {
+        if (j + 5 < nun) issue(S5);
+        if (j + 6 < nun) issue(SU);
+      }
+    }
+    if (do_bias) {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) an[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);
+      for (int c = 0; c < 5; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
     }
 #pragma unroll
     for (int jj = 0; jj < 7; ++jj) {
@@ -689,23 +712,31 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
 #endif
       bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
     }
-    if (a.has_bias && q == 0 && blk.y == 0) {
+#ifdef VMG_DIAG
+    if (!(a.dbg & 4))
+#endif
+    {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
+      for (int c = 0; c < 5; ++c) af[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);  // (behind the last MFMA that reads af[c])
     }
-    if ((j & 1) == 0) {  // behind the MFMAs: units j+5, j+6 -> the slots of units j-1 and j (free since this iteration's barrier)
-      const int s5 = su == 0 ? 5 : su - 1;
+    if (SYNC && h == 1) {
 #ifdef VMG_DIAG
       if (!(a.dbg & 1))
 #endif
       {
-        if (j + 5 < nun) issue(s5);
-        if (j + 6 < nun) issue(su);
+        if (j + 5 < nun) issue(S5);
+        if (j + 6 < nun) issue(SU);
       }
     }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) af[c] = an[c];
-    sn = sn == 5 ? 0 : sn + 1;
+    return true;
+  };
+  for (int base = 0; base < nun; base += 6) {
+    if (!unit(base + 0, std::integral_constant<int, 0>{})) break;
+    if (!unit(base + 1, std::integral_constant<int, 1>{})) break;
+    if (!unit(base + 2, std::integral_constant<int, 2>{})) break;
+    if (!unit(base + 3, std::integral_constant<int, 3>{})) break;
+    if (!unit(base + 4, std::integral_constant<int, 4>{})) break;
+    if (!unit(base + 5, std::integral_constant<int, 5>{})) break;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
