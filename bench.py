@@ -6,8 +6,9 @@
 Workload = BASELINE.json configs[1]: per-GPU batch 4 x 7 x 3 x 64 x 64, 4x SR, bf16 activations (fp32 accumulate,
 fp32 master weights), random-init weights, synthetic data resident in HBM before the timed region.  One "step" is one
 pass of the hot path over one batch.  Prints ONE JSON line on rank 0 with the whole-job LR-frames/s, the roofline
-object of the dominant kernel (live HIP-event timing of the bf16 conv3x3 144->144 implicit-GEMM kernel) and the CPU
-baseline (the oracle, i.e. this repo's CPU restatement, on a bounded sample).
+object of the dominant kernel (live HIP-event timing of the bf16 conv3x3 144->144 weight-streaming kernel) and the CPU
+baseline (the oracle, i.e. this repo's CPU restatement, on one step of the same batch).  --workload train_full / infer /
+train_vimeo run the per-GPU shards of BASELINE configs[2] / [3] / [4] (the last with bf16 weights).
 """
 import argparse
 import ctypes
@@ -32,6 +33,9 @@ WORKLOADS = {
                   name="VMG-REDS-few_levels train step, per-GPU batch 4x7x3x64x64 -> 4x SR (BASELINE configs[1])"),
     "train_full": dict(cfg="full", batch=1, frames=7, size=64, ch=112,
                        name="VMG-REDS full config train step, per-GPU batch 1x7x3x64x64 -> 4x SR (BASELINE configs[2]: 8 clips over 8 GPUs)"),
+    "train_vimeo": dict(cfg="few", batch=1, frames=7, size=(256, 448), ch=144,
+                        name="VMG-few_levels train step on the Vimeo stress shape, per-GPU batch 1x7x3x256x448 -> 4x SR, bf16 weights "
+                             "(BASELINE configs[4] without its fp8 weights: not built)"),
     "infer": dict(cfg="few", batch=1, frames=100, size=128, ch=144,
                   name="VMG-REDS-few_levels sliding-window inference, 100 x 180x320 -> 720x1280, windows 50/25, tiles 128/20 (BASELINE configs[3])"),
 }
@@ -46,7 +50,8 @@ def build_model(device, wl=None):
     from vmg_amd.data import REDS_FEW_LEVELS, REDS_FULL
     torch.manual_seed(0)
     infer = wl["frames"] > 50
-    m = vmg_amd.VMG(num_frames=50 if infer else wl["frames"], image_size=[wl["size"]] * 2, is_train=not infer, spynet_pretrained=None,
+    hw = list(wl["size"]) if isinstance(wl["size"], tuple) else [wl["size"]] * 2
+    m = vmg_amd.VMG(num_frames=50 if infer else wl["frames"], image_size=hw, is_train=not infer, spynet_pretrained=None,
                     compute_dtype=torch.bfloat16, **(REDS_FULL if wl["cfg"] == "full" else REDS_FEW_LEVELS))
     m.spynet = vmg_amd.SPyNet(None)  # the configs' SPyNet checkpoint is a download URL: random init, as stated in "data"
     m = m.to(device)
@@ -161,9 +166,10 @@ def main():
         k1_pixels = 2 * 1 * S * S
     else:
         step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
-        lrs = synthetic_clip(B, Tn, S, S, seed=1234 + rank, device=device)
+        Hh, Ww = S if isinstance(S, tuple) else (S, S)
+        lrs = synthetic_clip(B, Tn, Hh, Ww, seed=1234 + rank, device=device)
         hrs = synthetic_target(lrs, seed=4321 + rank)
-        k1_pixels = 2 * B * S * S  # one frame of every clip for BOTH direction sweeps (run in lockstep)
+        k1_pixels = 2 * B * Hh * Ww  # one frame of every clip for BOTH direction sweeps (run in lockstep)
     k1_flops = 2.0 * wl["ch"] * wl["ch"] * 9 * k1_pixels  # algorithmic FLOPs of one launch of the dominant kernel
 
     def barrier():
@@ -243,7 +249,7 @@ def main():
         "value": round(value, 3), "unit": "LR-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
-        "config": {"workload": wl["name"], "global_batch": world * B, "frames_per_clip": Tn, "lr_size": [S, S] if train else [180, 320],
+        "config": {"workload": wl["name"], "global_batch": world * B, "frames_per_clip": Tn, "lr_size": (list(S) if isinstance(S, tuple) else [S, S]) if train else [180, 320],
                    "parallelism": f"dp{world}", "per_gpu_value": round(value / world, 3), "launch": mode},
         "roofline": roofline,
     }
