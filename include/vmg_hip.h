@@ -252,6 +252,10 @@ int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, c
  * ---------------------------------------------------------------------------------------------- */
 int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode, float scale,
                      void* stream);
+/* out (G, C, 3) += scale * sum over the R rows of group g of a * {b0, b1, b2} (fp32, zero-initialised by the caller): the three branch sums of
+ * the MorphFC re-weighting backward from one pass over the gradient (reference: models/function.py:791-793 through autograd). */
+int vmg_group_reduce3(int dtype, const void* a, const void* b0, const void* b1, const void* b2, float* out, int G, int64_t R, int C, float scale,
+                      void* stream);
 int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add, float s,
                         void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream);
 

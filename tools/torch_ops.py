@@ -24,14 +24,14 @@ LEAF = ("aten::add_", "aten::add", "aten::zeros", "aten::zero_", "aten::fill_", 
         "aten::clone", "aten::contiguous", "aten::flip", "aten::sum", "aten::to", "aten::_to_copy", "aten::zeros_like", "aten::empty_like", "aten::div",
         "aten::sub", "aten::index", "aten::where", "aten::addmm", "aten::mm")
 for ev in prof.events():
-    if ev.name in LEAF and ev.cpu_parent is not None and not ev.cpu_parent.name.startswith("aten::"):
+    if ev.name in LEAF and (ev.cpu_parent is None or not ev.cpu_parent.name.startswith("aten::")):
         frame = "?"
         for f in ev.stack or []:
             if "vmg_amd/" in f or "bench.py" in f:
                 frame = f.split("/root/repo/")[-1] if "/root/repo/" in f else f
                 break
         if frame == "?":
-            frame = "(autograd engine) parent=" + ev.cpu_parent.name[:60]
+            frame = "(autograd engine) parent=" + (ev.cpu_parent.name[:60] if ev.cpu_parent is not None else "-")
         cnt[(ev.name, frame[:110])] += 1
 for (name, frame), c in cnt.most_common(70):
     print("%5d  %-18s %s" % (c, name, frame))

@@ -68,6 +68,53 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__
   }
 }
 
+// out (G, C, 3) += scale * sum_r a * {b0, b1, b2}: the three branch sums of the MorphFC re-weighting backward (d softmax-weights) from ONE
+// pass over dy (reference: models/function.py:791-793 through autograd).  Same blocking as group_reduce_kernel.
+template <typename T, int VN>
+__global__ __launch_bounds__(256) void group_reduce3_kernel(const T* __restrict__ a, const T* __restrict__ b0, const T* __restrict__ b1,
+                                                            const T* __restrict__ b2, float* __restrict__ out, int G, long long R, int C,
+                                                            float scale, int chunks) {
+  struct alignas(sizeof(T) * VN) Vec { T v[VN]; };
+  __shared__ float red[3 * VN * 256];
+  const int g = blockIdx.x / chunks, ck = blockIdx.x - g * chunks;
+  const int tpr = C / VN;
+  const int rpb = 256 / tpr;
+  const int roff = threadIdx.x / tpr, cp = threadIdx.x - roff * tpr;
+  const long long r0 = R * ck / chunks, r1 = R * (ck + 1) / chunks;
+  float s[3][VN];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int e = 0; e < VN; ++e) s[k][e] = 0.f;
+  if (roff < rpb) {
+    const long long base = (long long)g * R * C + VN * cp;
+    for (long long r = r0 + roff; r < r1; r += rpb) {
+      const long long o = base + r * C;
+      const Vec va = *reinterpret_cast<const Vec*>(a + o);
+      const Vec v0 = *reinterpret_cast<const Vec*>(b0 + o), v1 = *reinterpret_cast<const Vec*>(b1 + o), v2 = *reinterpret_cast<const Vec*>(b2 + o);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float d = to_f32(va.v[e]);
+        s[0][e] += d * to_f32(v0.v[e]);
+        s[1][e] += d * to_f32(v1.v[e]);
+        s[2][e] += d * to_f32(v2.v[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int e = 0; e < VN; ++e) red[(k * VN + e) * 256 + threadIdx.x] = s[k][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const int c = i / 3, k = i - 3 * c;
+    const int cp2 = c / VN, e = c - cp2 * VN;
+    float t = 0.f;
+    for (int j = 0; j < rpb; ++j) t += red[(k * VN + e) * 256 + j * tpr + cp2];
+    atomicAdd(out + ((long long)g * C + c) * 3 + k, t * scale);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ elementwise
 enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6 };
 
@@ -403,6 +450,26 @@ extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const v
       hipLaunchKernelGGL((group_reduce_kernel<float, 2>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3,
                          out, G, (long long)R, C, mode, scale, chunks);
   }
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_group_reduce3(int dtype, const void* a, const void* b0, const void* b1, const void* b2, float* out, int G, int64_t R, int C,
+                                 float scale, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "group_reduce3: bad dtype");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(a && b0 && b1 && b2 && out && G > 0 && R > 0 && C > 0 && C % vn == 0 && C / vn <= 256, "group_reduce3: bad arguments (C a multiple of %d)", vn);
+  VMG_CHECK((((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2) % 16) == 0, "group_reduce3: pointers must be 16-byte aligned");
+  int chunks = (int)(1024 / G);
+  if (chunks < 1) chunks = 1;
+  if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL((group_reduce3_kernel<bf16, 8>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b0, (const bf16*)b1,
+                       (const bf16*)b2, out, G, (long long)R, C, scale, chunks);
+  else
+    hipLaunchKernelGGL((group_reduce3_kernel<float, 4>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b0, (const float*)b1,
+                       (const float*)b2, out, G, (long long)R, C, scale, chunks);
   VMG_LAUNCH_CHECK();
   return 0;
 }

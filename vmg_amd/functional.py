@@ -718,14 +718,13 @@ class _ResidualDropPath(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, y, g):
         out = K.tab_elementwise(K.OP_CA_FWD, y.contiguous(), res.contiguous(), coef=g, s=1.0, G=g.shape[0])
-        ctx.save_for_backward(g)
-        ctx.bshape = (g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)
+        ctx.save_for_backward(g.reshape((g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)).to(y.dtype))  # (B, C): cast once, here
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (g,) = ctx.saved_tensors
-        return dy, dy * g.reshape(ctx.bshape).to(dy.dtype), None
+        (gb,) = ctx.saved_tensors
+        return dy, dy * gb, None
 
 
 def residual_drop_path(res: torch.Tensor, y: torch.Tensor, p: float, training: bool, scale: float = 1.0) -> torch.Tensor:
@@ -770,7 +769,7 @@ class _ReweightMix(torch.autograd.Function):
         R = ctx.R
         dy = dy.contiguous()
         B, C = h.shape[0], h.shape[-1]
-        da = torch.stack([K.group_reduce(dy, B, b=t, mode=1) for t in (h, w, c)], -1).reshape(B, 3 * C)  # (B,C,3)
+        da = K.group_reduce3(dy, h, w, c, B).reshape(B, 3 * C)  # (B,C,3): d loss / d softmax weights, one pass over dy
         into = tuple(DEFERRED.grad_of(p) for p in ctx.params) if ctx.direct else None
         dm, dw1, db1, dw2, db2 = K.se_mlp_backward(da, a, m, pre, fc1w, fc2w, hip.ACT_GELU, 1, 1.0 / R, into=into)   # softmax, Linear, GELU, Linear backward
         dh, dw, dc = K.tab_elementwise(K.OP_MIX_BWD, dy, coef=a, add=dm, G=B, nout=3)
@@ -947,8 +946,7 @@ class _LTAM(torch.autograd.Function):
         keys = list(ctx.saved_tensors[6:6 + t])
         vals = list(ctx.saved_tensors[6 + t:])
         dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale)
-        dt = q.dtype
-        return (dq, None, drpe, None, None, *[g.to(dt) for g in dk], *[g.to(dt) for g in dv])
+        return (dq, None, drpe, None, None, *dk, *dv)  # (already in q's dtype)
 
 
 def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vmg_pack_entry": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_int]),
     "vmg_pack_run": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vmg_group_reduce3": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, ctypes.c_float, c_void_p]),
     "vmg_se_mlp_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "vmg_se_mlp_bwd": (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.c_float, c_int, c_void_p]),
     "vmg_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -688,6 +688,10 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
     hip.check(hip.lib().vmg_ltam_bwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
                                      decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
                                      drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")
+    if q.dtype != torch.float32:  # ONE cast of the whole accumulator block instead of one per key / value frame
+        acc = acc.to(q.dtype)
+        dk = [acc[j] for j in range(t)]
+        dv = [acc[t + j] for j in range(t)]
     return dq, dk, dv, drpe
 
 
@@ -706,6 +710,19 @@ def group_reduce(a: torch.Tensor, G: int, b: Optional[torch.Tensor] = None, c3: 
     hip.check(hip.lib().vmg_group_reduce(hip.dtype_code(a.dtype), a.data_ptr(), b.data_ptr() if b is not None else None,
                                          c3.data_ptr() if c3 is not None else None, out.data_ptr(), G, rows // G, C, mode, scale,
                                          hip.stream_ptr()), "vmg_group_reduce")
+    return out
+
+
+def group_reduce3(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, G: int, scale: float = 1.0) -> torch.Tensor:
+    """fp32 (G, C, 3): scale * sum_r a * {b0, b1, b2} over the rows of each group, one pass over a."""
+    hip.require_cuda(a, b0, b1, b2)
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if rows % G or any(t.shape != a.shape or t.dtype != a.dtype or not t.is_contiguous() for t in (a, b0, b1, b2)):
+        raise HipError("group_reduce3: contiguous tensors of one shape / dtype covering G groups expected")
+    out = torch.zeros((G, C, 3), dtype=torch.float32, device=a.device)
+    hip.check(hip.lib().vmg_group_reduce3(hip.dtype_code(a.dtype), a.data_ptr(), b0.data_ptr(), b1.data_ptr(), b2.data_ptr(), out.data_ptr(), G,
+                                          rows // G, C, scale, hip.stream_ptr()), "vmg_group_reduce3")
     return out
 
 
