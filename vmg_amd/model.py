@@ -365,12 +365,16 @@ class Trajectory_multi_head(nn.Module):
         k_in: List[torch.Tensor] = []
         k_state: List[torch.Tensor] = []
         feats = []
+        # unbind / split instead of indexing: the backward of x[j] is a zero-filled tensor of the WHOLE stack per frame (66 MB each at the
+        # bench shape) summed pairwise by autograd; the backward of unbind is one stack
+        curs = xpair.unbind(0)
+        fls = flpair.unbind(0) if flpair is not None else ()
         for j in range(t):
-            cur = xpair[j]
+            cur = curs[j]
             if j == 0:
                 feat = torch.zeros_like(cur)
             else:
-                fl = flpair[j - 1]
+                fl = fls[j - 1]
                 feat = flow_warp_nhwc(feat, fl, "bilinear", "border")
                 loc = FH.warp_locations(loc, fl)
                 feat = self.LTAM(cur, k_in, feat, k_state, loc)
@@ -381,9 +385,9 @@ class Trajectory_multi_head(nn.Module):
                 k_state.append(feat)
                 k_in.append(cur)
             feats.append(feat)
-        outs = torch.stack(feats, 0)  # (t, 2n, h, w, c)
-        back = outs[:, :n].flip(0).contiguous()
-        fwd = outs[:, n:].contiguous()
+        halves = [f.split(n, 0) for f in feats]  # step j: (backward sweep at frame t-1-j, forward sweep at frame j)
+        back = torch.stack([hv[0] for hv in reversed(halves)], 0)  # (t, n, h, w, c), frame order
+        fwd = torch.stack([hv[1] for hv in halves], 0)
         out = conv(self.fusion, [back, xt, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
         return out.reshape(t, n, h, w, c).transpose(0, 1).contiguous()
 
