@@ -469,9 +469,10 @@ class TrainStep:
     def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2):
         """Capture one whole training step (forward, loss, backward, deferred weight gradients, AdamW) into a hipGraph.
 
-        The step launches ~8 000 small kernels; replaying them from a graph removes the Python / launch overhead that
-        otherwise rivals the GPU time.  Every weight pack must be recorded INSIDE the graph (weights change on each
-        replay), hence the pack cache is cleared first.  Single-GPU only: the bucketed all-reduce stays eager."""
+        Replaying the step's ~2 000 launches from a graph removes the Python / launch overhead.  The weight packs are rebuilt INSIDE the
+        graph by the one-launch repack that follows the optimizer (functional.repack_all), so the packs the warm-up steps left behind are
+        exactly what the first replay needs; packs that are made on demand (weights modified in place during the forward) are recorded
+        where they happen.  Single-GPU only: the bucketed all-reduce stays eager."""
         if self.reducer is not None:
             raise RuntimeError("graph capture is for the single-GPU step; the distributed step runs eagerly")
         from . import functional as FH
@@ -483,7 +484,8 @@ class TrainStep:
                 self._eager(*self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        FH.clear_pack_cache()
+        if not isinstance(self.opt, FlatAdamW):
+            FH.clear_pack_cache()  # (no repack_all in this path: every pack is recorded where it is first needed)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._loss = self._eager(*self._static)
