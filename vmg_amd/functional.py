@@ -238,7 +238,7 @@ class _DeferredWgrad:
             return
         self.ready.append(ent)
         if not self.hold:
-            self.drain()
+            self.drain(force=False)
 
     @staticmethod
     def _multi_sig(ent):
@@ -257,19 +257,28 @@ class _DeferredWgrad:
                 return None
         return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(x0.stride()), tuple(d0.stride()))
 
-    def drain(self):
-        """Launch the gradients of every complete parameter: parameters of one shape share launches (eight per launch)."""
+    def drain(self, force: bool = True):
+        """Launch the gradients of complete parameters: parameters of one shape share launches (eight per launch).  force = False (a
+        single parameter has just completed): shapes that can share a launch wait until eight of them are complete -- the two 3x3 convs
+        of every RCAB, one per TAB, then cost three launches per step instead of 24; everything still pending goes out when a residual
+        chain completes or the backward pass ends."""
         if not self.ready:
             return
         ready, self.ready = self.ready, []
         groups = {}
+        for ent in ready:
+            groups.setdefault(self._multi_sig(ent), []).append(ent)
+        if not force:
+            for sig in list(groups):
+                if sig is not None and len(groups[sig]) < 8:
+                    self.ready.extend(groups.pop(sig))
+            ready = [ent for ents in groups.values() for ent in ents]
         for ent in ready:
             weight, bias = ent[0], ent[1]
             if weight.grad is None:
                 weight.grad = torch.zeros_like(weight, dtype=torch.float32)
             if bias is not None and bias.requires_grad and bias.grad is None:
                 bias.grad = torch.zeros_like(bias, dtype=torch.float32)
-            groups.setdefault(self._multi_sig(ent), []).append(ent)
         for sig, ents in groups.items():
             if sig is None or len(ents) < 2:
                 for weight, bias, entries in ents:
