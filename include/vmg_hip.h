@@ -208,6 +208,11 @@ int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* 
 int vmg_conv_wgrad3_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin,
                           int64_t dy_ps, int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws,
                           int64_t ws_bytes, void* stream);
+/* The same for 1x1 convolutions / Linears (bf16; Cin, Cout and the pixel strides multiples of 8; at least 2 048 pixels per problem): x / dy
+ * hold nprob * npairs pointers over M pixels each, dW (O_total, I_total). */
+int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int64_t M, int64_t x_ps, int Cin, int64_t dy_ps,
+                            int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws,
+                            int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound, one pass, 16-byte vectors).

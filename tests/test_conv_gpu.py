@@ -547,3 +547,26 @@ def test_conv_wgrad3_multi_equals_single_launches():
         assert float((dW - dW1).abs().max()) <= tol, f"problem {i}"
         if db is not None:
             assert float((db - db1).abs().max()) <= 1e-4 * max(1.0, float(db1.abs().max())), f"problem {i} bias"
+
+
+def test_linear_wgrad2_multi_equals_single_launches():
+    """Ten Linear weight gradients of one shape (2 pairs each, own scale, some without bias) through vmg_linear_wgrad2_multi (8 + 2 per launch)
+    against the one-problem-per-launch path."""
+    hip, K, O, R = _setup()
+    M, Ci, Co, P = 5000, 144, 288, 2
+    dt = torch.bfloat16
+    probs, single = [], []
+    for i in range(10):
+        xs = [R.seeded((M, Ci), 100 + 10 * i + p).cuda().to(dt) for p in range(P)]
+        dys = [R.seeded((M, Co), 500 + 10 * i + p).cuda().to(dt) for p in range(P)]
+        dW0, db0 = R.seeded((Co, Ci), 900 + i).cuda(), (R.seeded((Co,), 950 + i).cuda() if i % 3 else None)
+        scale = 0.25 if i % 2 else 1.0
+        probs.append((xs, dys, dW0.clone(), db0.clone() if db0 is not None else None, scale))
+        dW1, db1 = dW0.clone(), (db0.clone() if db0 is not None else None)
+        K.conv_wgrad_batched(xs, dys, dW1, db1, 1, 1, 1, M, scale=scale)
+        single.append((dW1, db1))
+    K.linear_wgrad2_multi(probs, M)
+    for i, ((_, _, dW, db, _), (dW1, db1)) in enumerate(zip(probs, single)):
+        assert float((dW - dW1).abs().max()) <= 1e-4 * max(1.0, float(dW1.abs().max())), f"problem {i}"
+        if db is not None:
+            assert float((db - db1).abs().max()) <= 1e-4 * max(1.0, float(db1.abs().max())), f"problem {i} bias"

@@ -802,14 +802,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __
 // footprint (54 KiB) and register use allow two workgroups per CU, whose barrier bubbles overlap.  The pixel list is
 // cut into S slabs; partial tiles go to the workspace and the reduce kernel adds them to dW in slab order.
 struct Lgrad2K {
-  const char* x[WG_MAX_PAIRS];
-  const char* dy[WG_MAX_PAIRS];
-  int npairs;
+  const char* x[W3_MAX_PROBS * WG_MAX_PAIRS];   // [problem][pair]
+  const char* dy[W3_MAX_PROBS * WG_MAX_PAIRS];
+  int npairs, nprob;
   long long Mpair;   // pixels per pair
   long long Upair, U;  // 32-pixel units per pair / in total
   long long x_ps, dy_ps;
   int Cin, Cout;
-  float* slab;  // [S][ciblk][coblk][9 waves][10 tiles][64][4]
+  float* slab;  // [problem][S][ciblk][coblk][9 waves][10 tiles][64][4]
   int S, has_bias;
   int gx, gy;   // co / ci blocks (1-D grid of gx * gy * S workgroups, see xcd_slab_block)
 };
@@ -822,7 +822,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = wave / 3, it = wave - cg * 3;
-  const SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S);
+  SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S * a.nprob);
+  const int prob = blk.z / a.S, zz = blk.z;  // (several problems of one shape per launch, as in conv_wgrad3_kernel)
+  blk.z -= prob * a.S;
+  const char* const* xs = a.x + prob * WG_MAX_PAIRS;
+  const char* const* dys = a.dy + prob * WG_MAX_PAIRS;
   const int ob = blk.x * 144, ib = blk.y * 144;
   const long long u_lo = a.U * blk.z / a.S, u_hi = a.U * (blk.z + 1) / a.S;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
@@ -845,9 +849,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
   auto issue = [&](int buf) {
     const bool pok = ipix + p_l < a.Mpair;
     char* dyt = smem + buf * L2_BUF;
-    const char* s0 = (pok && c_dy) ? a.dy[ipair] + ipix * a.dy_ps * 2 + off_dy : zsrc;
+    const char* s0 = (pok && c_dy) ? dys[ipair] + ipix * a.dy_ps * 2 + off_dy : zsrc;
     glds16_hidden(s0, dyt + wave * 1024);
-    const char* s1 = (pok && c_x) ? a.x[ipair] + ipix * a.x_ps * 2 + off_x : zsrc;
+    const char* s1 = (pok && c_x) ? xs[ipair] + ipix * a.x_ps * 2 + off_x : zsrc;
     glds16_hidden(s1, dyt + L2_TILE_BYTES + wave * 1024);
     ipix += 32;
     if (ipix >= a.Mpair) { ipix = 0; ++ipair; }
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     buf = buf == 2 ? 0 : buf + 1;
   }
-  float* sl = a.slab + ((((long long)blk.z * a.gy + blk.y) * a.gx + blk.x) * W2_WAVES + wave) * (L2_TILES * 256);
+  float* sl = a.slab + ((((long long)zz * a.gy + blk.y) * a.gx + blk.x) * W2_WAVES + wave) * (L2_TILES * 256);
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -893,11 +897,14 @@ __global__ __launch_bounds__(W2_THREADS, 2) void linear_wgrad2_kernel(const Lgra
   }
 }
 
-__global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* __restrict__ slab, int S, int gx, int gy, int Cin, int Cout,
-                                                                   float* __restrict__ dW, int I_total, int o0, int i0,
-                                                                   float* __restrict__ db, float scale) {
+__global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* __restrict__ slab0, int S, int gx, int gy, int Cin, int Cout,
+                                                                   const Wgrad3Out outs, int I_total, int o0, int i0) {
   __shared__ float red[256];
   const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
+  const float* __restrict__ slab = slab0 + (long long)blockIdx.y * S * per_s;  // blockIdx.y = problem
+  float* __restrict__ dW = outs.dW[blockIdx.y];
+  float* __restrict__ db = outs.db[blockIdx.y];
+  const float scale = outs.scale[blockIdx.y];
   for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
     const long long i = e0 + (threadIdx.x & 63);
     const float sum = slab_sum_4waves(slab, per_s, S, i, true, red);
@@ -1190,6 +1197,64 @@ static int launch_wgrad3(int nprob, int npairs, const void* const* x, const void
   return 0;
 }
 
+// 1x1 / Linear weight gradients: one or several problems of one shape per launch.  Returns 1 when the large-tile path does not apply
+// (workspace too small, tiny problem): the caller falls back.
+static int launch_lgrad2(int nprob, int npairs, const void* const* x, const void* const* dy, long long Mpair, int64_t x_ps, int Cin, int64_t dy_ps,
+                         int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws,
+                         int64_t ws_bytes, void* stream) {
+  Lgrad2K k;
+  memset(&k, 0, sizeof(k));
+  Wgrad3Out outs;
+  memset(&outs, 0, sizeof(outs));
+  k.Mpair = Mpair;
+  k.Upair = (k.Mpair + 31) / 32; k.U = k.Upair * npairs;
+  const int gx = cdiv(Cout, 144), gy = cdiv(Cin, 144);
+  long long S = 512 / ((long long)gx * gy * nprob);  // two workgroups per CU over all problems
+  if (S > k.U / 8) S = k.U / 8;
+  if (S < 1) S = 1;
+  const long long need = (long long)nprob * S * gx * gy * L2_WG_FLOATS * 4;
+  if (need > ws_bytes || k.U < 64) return 1;  // (tiny problems: the v1 kernel's single launch is cheaper)
+  bool any_bias = false;
+  for (int q = 0; q < nprob; ++q) {
+    for (int p = 0; p < npairs; ++p) {
+      k.x[q * WG_MAX_PAIRS + p] = (const char*)x[q * npairs + p];
+      k.dy[q * WG_MAX_PAIRS + p] = (const char*)dy[q * npairs + p];
+    }
+    outs.dW[q] = dW[q];
+    outs.db[q] = db ? db[q] : nullptr;
+    outs.scale[q] = scales[q];
+    any_bias = any_bias || outs.db[q] != nullptr;
+  }
+  k.npairs = npairs; k.nprob = nprob; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.S = (int)S; k.slab = (float*)ws;
+  k.has_bias = any_bias;
+  k.gx = gx; k.gy = gy;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_wgrad2_kernel, dim3((unsigned)(gx * gy * S * nprob)), dim3(W2_THREADS), 3 * L2_BUF, st, k);
+  VMG_LAUNCH_CHECK();
+  const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
+  const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
+  hipLaunchKernelGGL(linear_wgrad2_reduce_kernel, dim3(rb, nprob), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, outs, I_total, o0, i0);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Several 1x1 / Linear weight gradients of ONE shape in one launch (the token mixers and projections of a TAB stage): x / dy hold
+// nprob * npairs pointers [problem][pair] over M pixels each, dW (O_total, I_total) / db one pointer and scales one factor per problem.
+extern "C" int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int64_t M, int64_t x_ps, int Cin,
+                                       int64_t dy_ps, int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db,
+                                       const float* scales, void* ws, int64_t ws_bytes, void* stream) {
+  VMG_CHECK(nprob >= 1 && nprob <= W3_MAX_PROBS && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && ws && scales, "linear_wgrad2_multi: 1..%d problems, 1..%d pairs",
+            W3_MAX_PROBS, WG_MAX_PAIRS);
+  VMG_CHECK(M > 0 && (x_ps % 8 == 0) && (dy_ps % 8 == 0) && (Cin % 8 == 0) && (Cout % 8 == 0) && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0,
+            "linear_wgrad2_multi: bf16 with 8-channel vectors only");
+  for (int p = 0; p < nprob * npairs; ++p)
+    VMG_CHECK(x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0), "linear_wgrad2_multi: null or unaligned pointer %d", p);
+  for (int p = 0; p < nprob; ++p) VMG_CHECK(dW[p], "linear_wgrad2_multi: null gradient pointer %d", p);
+  const int rc = launch_lgrad2(nprob, npairs, x, dy, M, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scales, ws, ws_bytes, stream);
+  VMG_CHECK(rc != 1, "linear_wgrad2_multi: problem too small for the large-tile kernel or workspace too small (use vmg_conv_wgrad_batched_ws)");
+  return rc;
+}
+
 extern "C" int64_t vmg_conv_wgrad_ws_bytes(void) { return 320LL * W3_WG_FLOATS * 4; }  // up to 320 workgroups of slabs (~94 MB)
 
 extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* x, const void* const* dy, int N, int H, int W,
@@ -1199,28 +1264,9 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
       (Cin % 8 == 0) && (Cout % 8 == 0) && x_ps >= Cin && dy_ps >= Cout && N > 0 && H > 0 && W > 0 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0) {
     bool al = true;
     for (int p = 0; al && p < npairs; ++p) al = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
-    Lgrad2K k;
-    memset(&k, 0, sizeof(k));
-    k.Mpair = (long long)N * H * W;
-    k.Upair = (k.Mpair + 31) / 32; k.U = k.Upair * npairs;
-    const int gx = cdiv(Cout, 144), gy = cdiv(Cin, 144);
-    long long S = 512 / ((long long)gx * gy);  // two workgroups per CU
-    if (S > k.U / 8) S = k.U / 8;
-    if (S < 1) S = 1;
-    const long long need = S * gx * gy * L2_WG_FLOATS * 4;
-    if (al && need <= ws_bytes && k.U >= 64) {  // (tiny problems: the v1 kernel's single launch is cheaper)
-      for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
-      k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.S = (int)S; k.slab = (float*)ws;
-      k.has_bias = db != nullptr;
-      k.gx = gx; k.gy = gy;
-      hipStream_t st = (hipStream_t)stream;
-      hipLaunchKernelGGL(linear_wgrad2_kernel, dim3((unsigned)(gx * gy * S)), dim3(W2_THREADS), 3 * L2_BUF, st, k);
-      VMG_LAUNCH_CHECK();
-      const long long per_s = (long long)gy * gx * L2_WG_FLOATS;
-      const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
-      hipLaunchKernelGGL(linear_wgrad2_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, dW, I_total, o0, i0, db, scale);
-      VMG_LAUNCH_CHECK();
-      return 0;
+    if (al) {
+      const int rc = launch_lgrad2(1, npairs, x, dy, (long long)N * H * W, x_ps, Cin, dy_ps, Cout, &dW, I_total, o0, i0, &db, &scale, ws, ws_bytes, stream);
+      if (rc <= 0) return rc;
     }
   }
   if (ws && dtype == VMG_BF16 && ks == 7 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && (x_ps % 8 == 0) && (Cin % 8 == 0) && x_ps >= Cin &&

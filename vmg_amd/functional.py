@@ -245,17 +245,18 @@ class _DeferredWgrad:
         """Signature under which complete parameters can share one vmg_conv_wgrad3_multi launch, or None."""
         weight, _, entries = ent
         e0 = entries[0]
-        if len(e0[1]) != 1 or e0[3] != 3 or weight.dim() != 4 or weight.shape[1] != e0[1][0]:
+        ks = e0[3]
+        if len(e0[1]) != 1 or ks not in (1, 3) or weight.shape[1] != e0[1][0] or (ks == 3 and weight.dim() != 4):
             return None
         x0, d0 = e0[0][0], e0[2]
-        if x0.shape[-1] != e0[1][0] or not K.conv_wgrad3_multi_ok(x0, d0, 3):
+        if x0.shape[-1] != e0[1][0] or not K.conv_wgrad3_multi_ok(x0, d0, ks):
             return None
         for e in entries:
             x, d = e[0][0], e[2]
             if e[1] != e0[1] or e[3:7] != e0[3:7] or e[7] != e0[7] or x.shape != x0.shape or d.shape != d0.shape or x.stride() != x0.stride() or \
-                    d.stride() != d0.stride() or not K.conv_wgrad3_multi_ok(x, d, 3):
+                    d.stride() != d0.stride() or not K.conv_wgrad3_multi_ok(x, d, ks):
                 return None
-        return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(x0.stride()), tuple(d0.stride()))
+        return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(x0.stride()), tuple(d0.stride()), ks)
 
     def drain(self, force: bool = True):
         """Launch the gradients of complete parameters: parameters of one shape share launches (eight per launch).  force = False (a
@@ -286,7 +287,10 @@ class _DeferredWgrad:
             else:
                 probs = [([e[0][0] for e in entries], [e[2] for e in entries], weight.grad,
                           bias.grad if (bias is not None and bias.requires_grad) else None, entries[0][7]) for weight, bias, entries in ents]
-                K.conv_wgrad3_multi(probs, sig[3], sig[4], sig[5])
+                if sig[8] == 3:
+                    K.conv_wgrad3_multi(probs, sig[3], sig[4], sig[5])
+                else:
+                    K.linear_wgrad2_multi(probs, sig[3] * sig[4] * sig[5])
         for weight, bias, _ in ready:
             for cb in self.callbacks:
                 cb(weight)

@@ -76,6 +76,8 @@ SIGNATURES = {
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_conv_wgrad3_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_linear_wgrad2_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_pack_entry_bytes": (c_int, []),
     "vmg_pack_entry": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_int]),

@@ -566,9 +566,45 @@ def conv_wgrad_batched(xs: Sequence[torch.Tensor], dys: Sequence[torch.Tensor], 
 
 
 def conv_wgrad3_multi_ok(x: torch.Tensor, dy: torch.Tensor, ks: int) -> bool:
-    """Shapes vmg_conv_wgrad3_multi takes: bf16, 3x3, pixel strides that are multiples of 8 channels, 16-byte aligned tensors."""
-    return (ks == 3 and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.stride(-1) == 1 and dy.stride(-1) == 1 and
+    """Shapes vmg_conv_wgrad3_multi / vmg_linear_wgrad2_multi take: bf16, 3x3 or 1x1, pixel strides that are multiples of 8 channels, 16-byte
+    aligned tensors (1x1: channel counts multiples of 8 and at least 2 048 pixels)."""
+    if ks == 1 and (x.shape[-1] % 8 or dy.shape[-1] % 8 or x.numel() // x.shape[-1] < 2048):
+        return False
+    return (ks in (1, 3) and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.stride(-1) == 1 and dy.stride(-1) == 1 and
             x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+
+
+def linear_wgrad2_multi(probs, M: int):
+    """probs: list of (xs, dys, dW (O, I[, 1, 1]), db, scale) of ONE shape: dW_i += scale_i * sum_p dys_i[p]^T xs_i[p] over M pixels, eight
+    problems per launch (vmg_linear_wgrad2_multi)."""
+    xs0, dys0, dW0 = probs[0][:3]
+    npairs = len(xs0)
+    Cin, Cout = xs0[0].shape[-1], dys0[0].shape[-1]
+    xps, dps = _pix_stride(xs0[0]), _pix_stride(dys0[0])
+    I_total = dW0.shape[1]
+    for xs, dys, dW, db, _ in probs:
+        hip.require_cuda(dW, db, *xs, *dys)
+        if len(xs) != npairs or len(dys) != npairs or dW.shape != dW0.shape or dW.dtype != torch.float32 or not dW.is_contiguous() or \
+                (db is not None and (db.dtype != torch.float32 or not db.is_contiguous() or db.numel() != dW.shape[0])):
+            raise HipError("linear_wgrad2_multi: problems must share the shape; gradients contiguous fp32")
+        for x, d in zip(xs, dys):
+            if x.dtype != torch.bfloat16 or d.dtype != torch.bfloat16 or x.shape[-1] != Cin or d.shape[-1] != Cout or x.numel() // Cin != M or \
+                    d.numel() // Cout != M or _pix_stride(x) != xps or _pix_stride(d) != dps:
+                raise HipError("linear_wgrad2_multi: all pairs must share shape, dtype and strides")
+    if dW0.shape[0] != Cout or Cin != I_total or dW0.numel() != Cout * Cin:
+        raise HipError("linear_wgrad2_multi: gradient tensor does not match the layer")
+    l = hip.lib()
+    ws = _wgrad_workspace(dW0.device)
+    for s in range(0, len(probs), 8):
+        grp = probs[s:s + 8]
+        n = len(grp)
+        xa = (ctypes.c_void_p * (n * npairs))(*[t.data_ptr() for g in grp for t in g[0]])
+        da = (ctypes.c_void_p * (n * npairs))(*[t.data_ptr() for g in grp for t in g[1]])
+        wa = (ctypes.c_void_p * n)(*[g[2].data_ptr() for g in grp])
+        ba = (ctypes.c_void_p * n)(*[(g[3].data_ptr() if g[3] is not None else None) for g in grp])
+        sa = (ctypes.c_float * n)(*[float(g[4]) for g in grp])
+        hip.check(l.vmg_linear_wgrad2_multi(n, npairs, xa, da, M, xps, Cin, dps, Cout, wa, I_total, 0, 0, ba, sa, ws.data_ptr(), ws.numel(),
+                                            hip.stream_ptr()), "vmg_linear_wgrad2_multi")
 
 
 def conv_wgrad3_multi(probs, N: int, H: int, W: int):
