@@ -7,7 +7,7 @@ from vmg_amd.data import synthetic_clip, synthetic_target
 from vmg_amd.train import TrainStep
 
 dev = torch.device("cuda", 0)
-torch.backends.cudnn.benchmark = True
+
 model = bench.build_model(dev)
 ts = TrainStep(model)
 x = synthetic_clip(4, 7, 64, 64, seed=1, device=dev)

@@ -60,8 +60,9 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
         return hit[1]
-    if hit is not None and hit[0][1] == ver[1]:
+    if hit is not None and hit[0][1] == ver[1] and key not in _PACK_VOLATILE:
         _PACK_VOLATILE.add(key)  # modified in place between optimizer steps (the MorphFC decay, T1): repack_all leaves it alone
+        _PACK_STAMP[0] += 1
     w = weight.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -96,35 +97,50 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
             pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
     else:
         raise HipError(kind)
-    _PACK_CACHE[key] = (ver, pw, weight)
+    if key not in _PACK_VOLATILE and pw.call is not None and pw.call[0] == weight.data_ptr():
+        _PACK_STAMP[0] += 1  # (a new or re-created pack that repack_all serves: its plan is rebuilt; packs of zero-padded copies and of
+        #                       weights modified in place are redone on demand every step and never enter the plan)
+    _PACK_CACHE[key] = [ver, pw, weight]
     return pw
 
 
 def clear_pack_cache():
     _PACK_CACHE.clear()
     _PACK_VOLATILE.clear()
+    _PACK_STAMP[0] += 1
 
 
 _PACK_VOLATILE = set()
 _PACK_PLAN = K.PackPlan()
 
 
+_PACK_STAMP = [0]   # bumped when the set of plan-eligible packs changes (new key, a key turned volatile, cache cleared)
+_PACK_STATE = {"stamp": -1, "ents": [], "packs": []}
+
+
 def repack_all():
     """Rebuild, in ONE launch, every cached pack whose source is the parameter itself (call right after the optimizer has written the
-    parameters): the next forward finds them current instead of launching ~390 small pack kernels one by one."""
-    live, packs = [], []
-    for key, (ver, pw, weight) in _PACK_CACHE.items():
-        if key in _PACK_VOLATILE or pw.call is None or pw.call[0] != weight.data_ptr():
-            continue  # (a zero-padded copy was packed, not the parameter: the on-demand path redoes it)
-        live.append(key)
-        packs.append(pw)
-    if not packs:
+    parameters): the next forward finds them current instead of launching ~390 small pack kernels one by one.  The list of packs is
+    rebuilt only when the cache's membership has changed -- this runs at the very end of a step, with the GPU idle behind it."""
+    st = _PACK_STATE
+    if st["stamp"] != _PACK_STAMP[0]:
+        ents, packs = [], []
+        for key, ent in _PACK_CACHE.items():
+            pw, weight = ent[1], ent[2]
+            if key in _PACK_VOLATILE or pw.call is None or pw.call[0] != weight.data_ptr():
+                continue  # (a zero-padded copy was packed, not the parameter: the on-demand path redoes it)
+            ents.append(ent)
+            packs.append(pw)
+        fresh = True
+        st["ents"], st["packs"], st["stamp"] = ents, packs, _PACK_STAMP[0]
+    else:
+        fresh = False
+    if not st["packs"]:
         return
-    _PACK_PLAN.run(packs)
+    _PACK_PLAN.run(st["packs"], reuse=not fresh)  # (fresh list: PackPlan compares addresses and re-uploads its entries only if they differ)
     ep = _WEIGHT_EPOCH[0]
-    for key in live:
-        _, pw, weight = _PACK_CACHE[key]
-        _PACK_CACHE[key] = ((weight._version, ep), pw, weight)
+    for ent in st["ents"]:
+        ent[0] = (ent[2]._version, ep)
 
 
 def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:

@@ -837,12 +837,16 @@ class PackPlan:
     def __init__(self):
         self.sig, self.dev, self.n, self.blocks = None, None, 0, 0
 
-    def run(self, packs: Sequence[PackedConv]):
+    def run(self, packs: Sequence[PackedConv], reuse: bool = False):
+        """reuse: the caller guarantees that `packs` is the list of the previous call unless it has reset self.sig to None."""
+        l = hip.lib()
+        if reuse and self.sig is not None:
+            hip.check(l.vmg_pack_run(self.dev.data_ptr(), self.n, self.blocks, hip.stream_ptr()), "vmg_pack_run")
+            return
         packs = [p for p in packs if p.call is not None]
         if not packs:
             return
         sig = tuple((p.call[0], p.buf.data_ptr()) for p in packs)
-        l = hip.lib()
         if sig != self.sig:
             esz = l.vmg_pack_entry_bytes()
             host = (ctypes.c_char * (esz * len(packs)))()
