@@ -139,6 +139,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk, int dbg) {
 
 // ---- stage the halo tile of source s in LDS: (THH rows) x (TWH pixels) x ch channels (all 256 threads; no barriers
 // inside -- the caller brackets it)
+// LDS-DMA as an asm statement (see conv_wgrad.hip::glds16_hidden): with the builtin, hipcc waits vmcnt(0) in front of every later ds_read of
+// the issuing wave, i.e. for the whole weight ring in flight; the kernels below count their copies by hand.
+__device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
+  unsigned keep;
+  const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+}
+
 template <typename T, int KS, int MT>
 __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, int n, int ty, int tx, long long m0, int tid) {
   constexpr int ES = ElemTraits<T>::ES;
@@ -175,7 +184,7 @@ __device__ __forceinline__ void stage_halo(const ConvK& a, int s, char* halo, in
           else ok = ok && (long long)(r * 16 + p) < mleft;
           const int off = r * rowstep + p * ps32 + v * 16;
           const char* gp = ok ? origin + off : reinterpret_cast<const char*>(&g_conv_zero16);
-          __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(halo + i0 * 16), 16, 0, 0);
+          glds16_asm(gp, halo + i0 * 16);
           rem += drem;
           r += dr;
           if (rem >= row_vecs) { rem -= row_vecs; ++r; }
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
     const char* gsrc = wsrc + (long long)stage * SS;
     char* dst = wbuf + (stage % RING) * SS + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + i * 4096), LDS_PTR(dst + i * 4096), 16, 0, 0);
+    for (int i = 0; i < IPW; ++i) glds16_asm(gsrc + i * 4096, dst + i * 4096);
   };
 
 #pragma unroll
