@@ -179,7 +179,8 @@ class _DeferredWgrad:
         self.callbacks = []  # called with each parameter whose .grad has just been completed
         self.managed = set()  # ids of the parameters (weights and their biases) whose gradient is completed HERE, not by autograd
         self._queued = False
-        self.ready = []     # [weight, bias, entries] whose last use has been seen: launched by drain()
+        self.ready = []     # [weight, bias, entries] whose last use has been seen, not batchable: launched by drain()
+        self.waiting = {}   # multi-launch signature -> complete parameters waiting for company (launched at eight, or by drain())
         self.hold = 0       # > 0: a node that completes many parameters at once (a residual chain) is collecting them
 
     def begin_forward(self):
@@ -252,13 +253,21 @@ class _DeferredWgrad:
         ent = self.pending.pop(id(weight), None)
         if ent is None:
             return
-        self.ready.append(ent)
-        if not self.hold:
-            self.drain(force=False)
+        sig = self._multi_sig(ent)  # computed ONCE per parameter and step (this runs on the autograd thread, with the GPU waiting behind it)
+        if sig is None:
+            if self.hold:
+                self.ready.append(ent)
+            else:
+                self._launch([ent], None)
+            return
+        lst = self.waiting.setdefault(sig, [])
+        lst.append(ent)
+        if len(lst) >= 8 and not self.hold:
+            self._launch(self.waiting.pop(sig), sig)
 
     @staticmethod
     def _multi_sig(ent):
-        """Signature under which complete parameters can share one vmg_conv_wgrad3_multi launch, or None."""
+        """Signature under which complete parameters can share one vmg_conv_wgrad3_multi / vmg_linear_wgrad2_multi launch, or None."""
         weight, _, entries = ent
         e0 = entries[0]
         ks = e0[3]
@@ -267,51 +276,47 @@ class _DeferredWgrad:
         x0, d0 = e0[0][0], e0[2]
         if x0.shape[-1] != e0[1][0] or not K.conv_wgrad3_multi_ok(x0, d0, ks):
             return None
-        for e in entries:
+        xs0, ds0, xt0, dt0, c0, m0 = x0.shape, d0.shape, x0.stride(), d0.stride(), e0[1], e0[3:8]
+        for e in entries[1:]:
             x, d = e[0][0], e[2]
-            if e[1] != e0[1] or e[3:7] != e0[3:7] or e[7] != e0[7] or x.shape != x0.shape or d.shape != d0.shape or x.stride() != x0.stride() or \
-                    d.stride() != d0.stride() or not K.conv_wgrad3_multi_ok(x, d, ks):
+            if e[1] != c0 or e[3:8] != m0 or x.shape != xs0 or d.shape != ds0 or x.stride() != xt0 or d.stride() != dt0 or not K.conv_wgrad3_multi_ok(x, d, ks):
                 return None
-        return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(x0.stride()), tuple(d0.stride()), ks)
+        return (tuple(weight.shape), len(entries), e0[1], e0[4], e0[5], e0[6], tuple(xt0), tuple(dt0), ks)
 
-    def drain(self, force: bool = True):
-        """Launch the gradients of complete parameters: parameters of one shape share launches (eight per launch).  force = False (a
-        single parameter has just completed): shapes that can share a launch wait until eight of them are complete -- the two 3x3 convs
-        of every RCAB, one per TAB, then cost three launches per step instead of 24; everything still pending goes out when a residual
-        chain completes or the backward pass ends."""
-        if not self.ready:
-            return
-        ready, self.ready = self.ready, []
-        groups = {}
-        for ent in ready:
-            groups.setdefault(self._multi_sig(ent), []).append(ent)
-        if not force:
-            for sig in list(groups):
-                if sig is not None and len(groups[sig]) < 8:
-                    self.ready.extend(groups.pop(sig))
-            ready = [ent for ents in groups.values() for ent in ents]
-        for ent in ready:
-            weight, bias = ent[0], ent[1]
+    def _launch(self, ents, sig):
+        """The gradients of the complete parameters `ents`: one by one (sig None or a single parameter) or eight per launch."""
+        for weight, bias, _ in ents:
             if weight.grad is None:
                 weight.grad = torch.zeros_like(weight, dtype=torch.float32)
             if bias is not None and bias.requires_grad and bias.grad is None:
                 bias.grad = torch.zeros_like(bias, dtype=torch.float32)
-        for sig, ents in groups.items():
-            if sig is None or len(ents) < 2:
-                for weight, bias, entries in ents:
-                    _wgrad_entries(entries, weight.grad, bias.grad if (bias is not None and bias.requires_grad) else None)
+        if sig is None or len(ents) < 2:
+            for weight, bias, entries in ents:
+                _wgrad_entries(entries, weight.grad, bias.grad if (bias is not None and bias.requires_grad) else None)
+        else:
+            probs = [([e[0][0] for e in entries], [e[2] for e in entries], weight.grad,
+                      bias.grad if (bias is not None and bias.requires_grad) else None, entries[0][7]) for weight, bias, entries in ents]
+            if sig[8] == 3:
+                K.conv_wgrad3_multi(probs, sig[3], sig[4], sig[5])
             else:
-                probs = [([e[0][0] for e in entries], [e[2] for e in entries], weight.grad,
-                          bias.grad if (bias is not None and bias.requires_grad) else None, entries[0][7]) for weight, bias, entries in ents]
-                if sig[8] == 3:
-                    K.conv_wgrad3_multi(probs, sig[3], sig[4], sig[5])
-                else:
-                    K.linear_wgrad2_multi(probs, sig[3] * sig[4] * sig[5])
-        for weight, bias, _ in ready:
+                K.linear_wgrad2_multi(probs, sig[3] * sig[4] * sig[5])
+        for weight, bias, _ in ents:
             for cb in self.callbacks:
                 cb(weight)
                 if bias is not None and bias.requires_grad:
                     cb(bias)
+
+    def drain(self):
+        """Launch everything that is complete: parameters of one shape share launches (eight per launch).  Between drains (a residual
+        chain completing, the end of the backward pass) shapes that can share a launch wait in `waiting` until eight of them are complete
+        -- the two 3x3 convs of every RCAB, one per TAB, cost three launches per step instead of 24."""
+        if self.ready:
+            ready, self.ready = self.ready, []
+            self._launch(ready, None)
+        if self.waiting:
+            waiting, self.waiting = self.waiting, {}
+            for sig, ents in waiting.items():
+                self._launch(ents, sig)
 
     def flush_all(self):
         self._end_of_backward()

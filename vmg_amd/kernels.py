@@ -245,8 +245,8 @@ def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: to
     for b in [b0] + list(b1) + list(b2):
         if b.dtype != torch.float32 or b.numel() != C or not b.is_contiguous():
             raise HipError("resblock_chain: biases must be contiguous fp32 of length C")
-    ys = [torch.empty((N, H, W, C), dtype=dt, device=x0.device) for _ in range(nblk + 1)]
-    ts = [torch.empty((N, H, W, C), dtype=dt, device=x0.device) for _ in range(nblk)]
+    blk = torch.empty((2 * nblk + 1, N, H, W, C), dtype=dt, device=x0.device).unbind(0)  # ONE allocation: 31 torch.empty calls cost 0.1 ms of host time per chain
+    ys, ts = list(blk[:nblk + 1]), list(blk[nblk + 1:])
     d = hip.ChainDesc()
     d.dtype, d.N, d.H, d.W, d.C, d.nblk, d.nsrc = hip.dtype_code(dt), N, H, W, C, nblk, len(srcs)
     for i, s in enumerate(srcs):
@@ -270,10 +270,10 @@ def resblock_chain_backward(g: torch.Tensor, ts: Sequence[torch.Tensor], pd1: Se
     nblk = len(ts)
     N, H, W, C = g.shape
     g = g.contiguous()
-    gys = [torch.empty_like(g) for _ in range(nblk)] + [g]
-    gts = [torch.empty_like(g) for _ in range(nblk)]
     if nblk == 0:
-        return gys, gts
+        return [g], []
+    blk = torch.empty((2 * nblk, N, H, W, C), dtype=g.dtype, device=g.device).unbind(0)
+    gys, gts = list(blk[:nblk]) + [g], list(blk[nblk:])
     d = hip.ChainDesc()
     d.dtype, d.N, d.H, d.W, d.C, d.nblk, d.nsrc = hip.dtype_code(g.dtype), N, H, W, C, nblk, 1
     keep = [_parr([p.buf for p in pd1]), _parr([p.buf for p in pd2]), _parr(list(ts)), _parr(gys), _parr(gts)]
