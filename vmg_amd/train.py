@@ -381,9 +381,14 @@ class FlatAdamW:
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are persistent views of the flat buffer: one memset (set_to_none is accepted and ignored)."""
         self.g.zero_()
-        for p, o in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:  # someone replaced the view: re-attach
-                p.grad = self.g[o:o + p.numel()].view_as(p)
+        views = getattr(self, "_grad_views", None)
+        if views is None or len(views) != len(self.params) or self._grad_views_of is not self.g:
+            views = self._grad_views = [None] * len(self.params)
+            self._grad_views_of = self.g
+        for i, p in enumerate(self.params):
+            if p.grad is not views[i]:  # (identity test: 560 data_ptr() comparisons cost 0.4 ms at every step boundary, GPU idle behind them)
+                o = self.offsets[i]
+                views[i] = p.grad = self.g[o:o + p.numel()].view_as(p)
 
     def _upload(self):
         b1, b2 = self.betas
