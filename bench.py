@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
                     "HIP-event roofline needs eager launches, so eager is the default)")
+    ap.add_argument("--replay", action="store_true", help="with --graph: re-issue the captured launches with plain hipLaunchKernel calls "
+                    "(vmg_replay_run) instead of hipGraphLaunch -- a measurement of the launch path only (+1 %), see TrainStep.capture")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -181,8 +183,8 @@ def main():
     mode = "eager"
     if use_graph:
         try:
-            step.capture(lrs, hrs, warmup=max(1, args.warmup))
-            mode = "hipgraph"
+            step.capture(lrs, hrs, warmup=max(1, args.warmup), replayer=args.replay)
+            mode = "captured step, plain launches (vmg_replay_run)" if args.replay else "hipgraph"
         except Exception as e:  # capture is an optimisation, never a requirement
             print("[bench] graph capture failed (%s: %s); running eagerly" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
             step.graph = None

@@ -159,6 +159,15 @@ typedef struct vmg_chain_desc {
 int vmg_resblock_chain_fwd(const vmg_chain_desc* d, void* stream);
 int vmg_resblock_chain_bwd(const vmg_chain_desc* d, void* stream);
 
+/* ---- replaying a captured step without the hipGraph executor (vmg_amd.train.TrainStep.capture).  hipGraphLaunch on ROCm 7 costs per node
+ * what the eager Python step costs; a one-stream capture is a linear list of kernel / memcpy / memset nodes, which vmg_replay_build reads
+ * out of the hipGraph_t (it must stay alive) and vmg_replay_run re-issues, op first .. last-1, with plain launches on `stream`.
+ * vmg_replay_kernel_info lets the caller find marker kernels (segment boundaries of a data-parallel step). */
+void* vmg_replay_build(void* hip_graph, int* n_ops, int* n_kernels);
+int vmg_replay_kernel_info(void* replay, int idx, void** func, unsigned* grid_x, unsigned* block_x, void** first_arg);
+int vmg_replay_run(void* replay, int first, int last, void* stream);
+void vmg_replay_destroy(void* replay);
+
 /* ---- batched packing: after an optimizer step every weight needs its packs rebuilt -- ~390 launches of 4 us in VMG-REDS-few_levels.
  * A PLAN is an array of vmg_pack_entry_bytes()-sized opaque entries in DEVICE memory, each holding the arguments of one
  * vmg_conv_pack (kind 0) / vmg_convws_pack (kind 1) call.  vmg_pack_entry fills one entry in HOST memory (the caller copies the array to

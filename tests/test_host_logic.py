@@ -160,7 +160,7 @@ def test_abi_argument_counts_match_the_header():
     from vmg_amd import hip
     hdr = open(os.path.join(ROOT, "include", "vmg_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    protos = re.findall(r"\b(?:int|int64_t|double|const char\*|vmg_ctx\*)\s+(vmg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|double|const char\*|vmg_ctx\*|void\*|void)\s+(vmg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
     assert len(protos) == len(hip.SIGNATURES)
     for name, args in protos:
         args = args.strip()

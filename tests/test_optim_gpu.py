@@ -104,3 +104,43 @@ def test_charbonnier_edge_loss_kernels(shape):
         _, ref = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
         got = charbonnier_edge_loss_hip(inp["x"].cuda(), inp["y"].cuda())
         assert abs(float(got) - float(ref[0]["sub"][0])) <= 2e-6 * max(1.0, abs(float(ref[0]["sub"][0])))
+
+
+def test_replay_of_a_captured_sequence_matches_the_graph():
+    """csrc/replay.hip: the kernel / memset nodes of a captured stream are read out of the hipGraph and re-issued with plain launches; the
+    result must equal what torch's own graph replay produces (elementwise kernels, a fill, a HIP-library kernel)."""
+    import ctypes
+    from vmg_amd import hip, kernels as K
+    x = torch.randn(4, 16, 16, 32, device="cuda").to(torch.bfloat16)
+    y = torch.randn(4, 16, 16, 32, device="cuda").to(torch.bfloat16)
+    out = torch.zeros(4, 16, 16, 32, device="cuda", dtype=torch.bfloat16)
+
+    def body():
+        t = K.act_backward(x, y, hip.ACT_RELU, 0.0, 1.0)
+        u = (t.float() * 2 + 1).to(torch.bfloat16)
+        out.zero_()
+        out.add_(u)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        body()
+    n_ops, n_k = ctypes.c_int(0), ctypes.c_int(0)
+    h = hip.lib().vmg_replay_build(ctypes.c_void_p(int(g.raw_cuda_graph())), ctypes.byref(n_ops), ctypes.byref(n_k))
+    assert h, hip.lib().vmg_last_error().decode()
+    assert n_k.value >= 3 and n_ops.value >= n_k.value
+    out.fill_(7)
+    x.mul_(-1)  # new inputs: the replay must recompute from them
+    hip.check(hip.lib().vmg_replay_run(ctypes.c_void_p(h), 0, n_ops.value, hip.stream_ptr()), "vmg_replay_run")
+    torch.cuda.synchronize()
+    got = out.clone()
+    out.fill_(7)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, out)
+    hip.lib().vmg_replay_destroy(ctypes.c_void_p(h))

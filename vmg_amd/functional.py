@@ -17,6 +17,16 @@ from .hip import HipError
 # ---------------------------------------------------------------------------------------------------------
 # packed-weight cache: (id(param), kind, dtype, slices) -> (version, PackedConv)
 # ---------------------------------------------------------------------------------------------------------
+class _Fn(torch.autograd.Function):
+    """torch.autograd.Function whose apply() skips the functorch bookkeeping (setup_context probing, dead-wrapper unwrapping of every
+    argument): ~4 us per node and ~300 nodes per step on a host-bound step.  functorch transforms (vmap, functional grad) are not
+    supported through these nodes -- the kernels are not batched-tensor aware anyway."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(torch.autograd.Function, cls).apply(*args)
+
+
 _PACK_CACHE = {}
 
 
@@ -76,12 +86,16 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
             # zero-pad each slice of the K dimension to a multiple of 8 channels
             parts, off = [], 0
             for c in src_ch:
-                sl = w[:, off:off + c]
-                if c % 8:
-                    sl = torch.cat([sl, sl.new_zeros(O, _pad_to(c) - c, *w.shape[2:])], 1)
-                parts.append(sl)
+                parts.append((off, c))
                 off += c
-            w = torch.cat(parts, 1)
+            # (slice assignment into one zero tensor, not torch.cat: cat of contiguous pieces is a device-to-device memcpy, which a
+            #  captured step cannot hand to csrc/replay.hip -- hipGraphMemcpyNodeGetParams does not describe 1-D copy nodes)
+            wp = w.new_zeros(O, sum(_pad_to(c) for _, c in parts), *w.shape[2:])
+            po = 0
+            for o_, c in parts:
+                wp[:, po:po + c] = w[:, o_:o_ + c]
+                po += _pad_to(c)
+            w = wp
             src_ch = [_pad_to(c) for c in src_ch]
         if deep == 3:
             pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles)
@@ -90,7 +104,9 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
     elif kind == "dgrad":
         on = I - i0 if on is None else on
         if O % 8:
-            w = torch.cat([w, w.new_zeros(_pad_to(O) - O, *w.shape[1:])], 0)
+            wp = w.new_zeros(_pad_to(O), *w.shape[1:])
+            wp[:O].add_(w)  # (an add kernel into the zeros: a contiguous copy_ would be a memcpy node, see the forward pack)
+            w = wp
         if deep == 3:
             pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
         else:
@@ -372,7 +388,7 @@ def _act_grad(dy: torch.Tensor, y: Optional[torch.Tensor], pre: Optional[torch.T
     return K.act_backward(dy, pre if act == hip.ACT_GELU else y, act, slope, alpha)
 
 
-class _Conv2d(torch.autograd.Function):
+class _Conv2d(_Fn):
     """out = [res +] alpha * act(conv(cat(srcs)) + bias), optional PixelShuffle(2) store."""
 
     @staticmethod
@@ -450,7 +466,7 @@ def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     return _Conv2d.apply(weight, bias, res, cfg, *srcs)
 
 
-class _ResidualChain(torch.autograd.Function):
+class _ResidualChain(_Fn):
     """ResidualBlocksWithInputConv (models/trajectory.py:16-52, 165-221) as ONE autograd node:
         y0 = lrelu_0.1(conv0(cat(srcs)));  y_{k+1} = y_k + r * conv2_k(relu(conv1_k(y_k)))
     Forward is the same fused-epilogue conv launches as the generic path; the point is the BACKWARD, which runs the
@@ -553,7 +569,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return out.reshape(*x.shape[:-1], weight.shape[0])
 
 
-class _LayerNorm(torch.autograd.Function):
+class _LayerNorm(_Fn):
     @staticmethod
     def forward(ctx, x, w, b, eps):
         x = x.contiguous()
@@ -575,7 +591,7 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
-class _SpaceDepthLayerNorm(torch.autograd.Function):
+class _SpaceDepthLayerNorm(_Fn):
     """UpdownkeepSampling's space<->depth rearrangement fused into its LayerNorm (models/layers.py:785-793): rows are gathered from
     the feature map in the forward and their gradient is scattered back in the backward -- no rearranged copy either way."""
 
@@ -623,6 +639,29 @@ import math
 import torch.nn.functional as F
 
 
+class _SplitHalves(_Fn):
+    """x (2n, ...) -> (x[:n], x[n:]) as fresh tensors; the backward writes both gradients into one tensor with elementwise kernels.  Plain
+    slicing has a SliceBackward that copies each gradient into a zero tensor with a device-to-device memcpy, which a captured step cannot
+    hand to csrc/replay.hip (used on the small flow fields of VMG.compute_flow)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.shape[0] // 2
+        return torch.mul(x[:n], 1), torch.mul(x[n:], 1)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n = ga.shape[0]
+        out = ga.new_empty((2 * n,) + tuple(ga.shape[1:]))
+        torch.mul(ga, 1, out=out[:n])
+        torch.mul(gb, 1, out=out[n:])
+        return out
+
+
+def split_halves(x: torch.Tensor):
+    return _SplitHalves.apply(x)
+
+
 def morph_tokens(x: torch.Tensor, axis: str, chunk: int, Cp: int) -> torch.Tensor:
     """Token layout of the H-/W-branch (models/function.py:763-764, 776-777): pad C->Cp and the mixed axis to a
     multiple of `chunk`; token (group, k) gets features f = p*S + s <- x[position p of the group, channel k*S + s]."""
@@ -630,11 +669,11 @@ def morph_tokens(x: torch.Tensor, axis: str, chunk: int, Cp: int) -> torch.Tenso
     S = Cp // chunk
     if axis == "h":
         Hp = int(math.ceil(H / chunk)) * chunk
-        xp = F.pad(x, (0, Cp - C, 0, 0, 0, Hp - H)).transpose(2, 3)
+        xp = (F.pad(x, (0, Cp - C, 0, 0, 0, Hp - H)) if (Cp != C or Hp != H) else x).transpose(2, 3)  # (F.pad by nothing is a full copy)
         L = W * Hp
     else:
         Wp = int(math.ceil(W / chunk)) * chunk
-        xp = F.pad(x, (0, Cp - C, 0, Wp - W))
+        xp = F.pad(x, (0, Cp - C, 0, Wp - W)) if (Cp != C or Wp != W) else x
         L = H * Wp
     t = xp.reshape(B, T, L // chunk, chunk, chunk, S)
     return t.permute(0, 1, 2, 4, 3, 5).reshape(B, T, L // chunk, chunk, chunk * S).contiguous()
@@ -652,7 +691,7 @@ def morph_untokens(t: torch.Tensor, axis: str, chunk: int, Cp: int, H: int, W: i
     return u.reshape(B, T, H, Wp, Cp)[..., 0:W, :C].contiguous()
 
 
-class _MorphLinear(torch.autograd.Function):
+class _MorphLinear(_Fn):
     """One MorphFC branch: relu(tokens(x) W^T + b) / Cp back in pixel layout (models/function.py:763-772, 776-785) as ONE kernel with the
     token reshuffle in the GEMM's addressing (vmg_morphfc_fwd).  Backward: the data gradient is the same kernel on (dy * relu'(y) / Cp)
     with the transposed weight; only the weight gradient still needs the two token matrices (gathered here, summed by the batched
@@ -705,7 +744,7 @@ def morph_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return morph_untokens(t, axis, chunk, Cp, H, W, C)
 
 
-class _ChannelAttention(torch.autograd.Function):
+class _ChannelAttention(_Fn):
     """(r * sigmoid(W2 relu(W1 GAP(r) + b1) + b2) + x) * s on (N,H,W,C): CALayer + RCAB residual (models/function.py:555-558,
     581).  The two full-tensor passes (GAP reduction, scale+residual) are HIP kernels; the (N,C)-sized squeeze-excite MLP
     and its backward are a handful of tiny fp32 ops."""
@@ -744,7 +783,7 @@ class _ChannelAttention(torch.autograd.Function):
 def channel_attention_residual(r, x, w1, b1, w2, b2, out_scale: float):
     return _ChannelAttention.apply(r, x, w1, b1, w2, b2, float(out_scale))
 
-class _ResidualDropPath(torch.autograd.Function):
+class _ResidualDropPath(_Fn):
     """res + y * g with g a per-(sample, channel) fp32 coefficient: the TAB residuals `x + DropPath(y) * s`
     (models/function.py:1212-1217) in ONE pass (HIP, the channel-attention scale kernel) instead of mask-multiply, scale and
     add; the backward is one multiply (d_res is dy itself)."""
@@ -778,7 +817,7 @@ def residual_drop_path(res: torch.Tensor, y: torch.Tensor, p: float, training: b
 
 
 
-class _ReweightMix(torch.autograd.Function):
+class _ReweightMix(_Fn):
     """Softmax re-weighting of the three mixer branches (models/function.py:791-793):
     a = softmax_3(Mlp(mean_{T,H,W}(h + w + c)));  y = h*a0 + w*a1 + c*a2."""
 
@@ -817,7 +856,7 @@ def reweight_mix(h, w, c, fc1w, fc1b, fc2w, fc2b):
     return _ReweightMix.apply(h, w, c, fc1w, fc1b, fc2w, fc2b)
 
 
-class _TanhGate(torch.autograd.Function):
+class _TanhGate(_Fn):
     """(x + y) * tanh(y) (models/function.py:801-802)."""
 
     @staticmethod
@@ -837,7 +876,7 @@ def tanh_gate(x, y):
     return _TanhGate.apply(x, y)
 
 
-class _MaxPool(torch.autograd.Function):
+class _MaxPool(_Fn):
     @staticmethod
     def forward(ctx, x, f):
         y, idx = K.maxpool_forward(x.contiguous(), f)
@@ -856,7 +895,7 @@ def max_pool(x: torch.Tensor, f: int) -> torch.Tensor:
     return _MaxPool.apply(x, int(f))
 
 
-class _GroupNorm1ReLU(torch.autograd.Function):
+class _GroupNorm1ReLU(_Fn):
     """relu(GroupNorm(1, C)(x)) on channels-last (n,h,w,c): per-sample statistics over (h,w,c), per-channel affine
     (models/vmg.py:390-399).  Two grouped reductions + one coefficient-broadcast elementwise pass each way; the (n, c)-sized
     algebra in between is a handful of tiny fp32 ops."""
@@ -898,7 +937,7 @@ def group_norm1_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: flo
     return _GroupNorm1ReLU.apply(x, w, b, float(eps))
 
 
-class _Upsample2xAC(torch.autograd.Function):
+class _Upsample2xAC(_Fn):
     """scale * F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) on channels-last fp32 (SPyNet's flow between
     pyramid levels, models/vmg.py:97-102)."""
 
@@ -927,7 +966,7 @@ def _norm_grid(g, h, w):
     return torch.stack((gx, gy), -1)
 
 
-class _WarpBilinear(torch.autograd.Function):
+class _WarpBilinear(_Fn):
     @staticmethod
     def forward(ctx, x, flow):
         x = x.contiguous()
@@ -956,7 +995,7 @@ def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
     return K.warp_nearest_planes(loc.detach(), flow.detach().contiguous())
 
 
-class _LTAM(torch.autograd.Function):
+class _LTAM(_Fn):
     @staticmethod
     def forward(ctx, q, loc, rpe, decay_v, cfg, *kv):
         heads, wh, ww, scale = cfg
@@ -989,7 +1028,7 @@ def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: in
 
 
 # ---- 3-D shifted-window attention (models/swin_3d.py) --------------------------------------------------
-class _Win3dAttention(torch.autograd.Function):
+class _Win3dAttention(_Fn):
     """rWindowAttention.attention for every window / head / time slice (swin_3d.py:167-252) with window partition, roll, padding,
     mask and bias gather folded into the kernel's addressing (vmg_win3d_attn_fwd / _bwd)."""
 

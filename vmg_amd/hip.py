@@ -78,6 +78,10 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_linear_wgrad2_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_replay_build": (c_void_p, [c_void_p, c_void_p, c_void_p]),
+    "vmg_replay_kernel_info": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vmg_replay_run": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vmg_replay_destroy": (None, [c_void_p]),
     "vmg_pack_entry_bytes": (c_int, []),
     "vmg_pack_entry": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_int]),

@@ -681,7 +681,8 @@ class VMG(nn.Module):
                 fb = ff.flip(1)
             else:  # both directions in ONE SPyNet pass (twice the batch, half the launches; per-sample results unchanged)
                 both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0), self.compute_dtype).contiguous()
-                ff, fb = both[:a.shape[0]].reshape(B, T - 1, 2, h, w), both[a.shape[0]:].reshape(B, T - 1, 2, h, w)
+                ff, fb = FH.split_halves(both)
+                ff, fb = ff.reshape(B, T - 1, 2, h, w), fb.reshape(B, T - 1, 2, h, w)
             fwd.append(ff)
             bwd.append(fb)
         return fwd, bwd
@@ -750,7 +751,9 @@ class VMG(nn.Module):
         N = B * D
         if self.local_fuse:
             y = conv(self.local_cnn, [y], N, Hp, Wp, res=feat.reshape(N, Hp, Wp, -1))
-        y = y.reshape(N, Hp, Wp, -1)[:, :H, :W].contiguous()
+        y = y.reshape(N, Hp, Wp, -1)
+        if (Hp, Wp) != (H, W):
+            y = y[:, :H, :W].contiguous()
         o = conv(self.upconv1, [y], N, H, W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
         o = conv(self.upconv2, [o], N, 2 * H, 2 * W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
         o = conv(self.HRconv, [o], N, 4 * H, 4 * W, act=ACT_LRELU, slope=0.1)

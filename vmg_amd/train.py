@@ -8,6 +8,7 @@ from gradient hooks while backward is still running.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Iterable, List, Optional
 
@@ -471,7 +472,7 @@ class TrainStep:
         from . import functional as FH
         FH.flush_deferred_wgrads()
 
-    def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2):
+    def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2, replayer: bool = False):
         """Capture one whole training step (forward, loss, backward, deferred weight gradients, AdamW) into a hipGraph.
 
         Replaying the step's ~2 000 launches from a graph removes the Python / launch overhead.  The weight packs are rebuilt INSIDE the
@@ -491,9 +492,21 @@ class TrainStep:
         torch.cuda.synchronize()
         if not isinstance(self.opt, FlatAdamW):
             FH.clear_pack_cache()  # (no repack_all in this path: every pack is recorded where it is first needed)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=replayer)
         with torch.cuda.graph(self.graph):
             self._loss = self._eager(*self._static)
+        self._replay = None
+        if replayer:
+            # experiment (bench.py --replay): read the captured launches out of the graph and re-issue them with plain launches
+            # (csrc/replay.hip) instead of hipGraphLaunch.  Measured: 497 vs 492 LR-frames/s eager -- the step is bound by the GPU and its
+            # ~2 700 kernel boundaries, not by whoever issues the launches.  NOT for training: torch's replay() advances the Philox offset
+            # of the captured DropPath masks, this path does not (the masks of the captured step repeat).
+            from . import hip
+            n_ops, n_k = ctypes.c_int(0), ctypes.c_int(0)
+            h = hip.lib().vmg_replay_build(ctypes.c_void_p(int(self.graph.raw_cuda_graph())), ctypes.byref(n_ops), ctypes.byref(n_k))
+            if not h:
+                raise hip.HipError("vmg_replay_build: " + hip.lib().vmg_last_error().decode())
+            self._replay, self._replay_ops, self._replay_kernels = ctypes.c_void_p(h), n_ops.value, n_k.value
         return self
 
     def replay(self, lrs: Optional[torch.Tensor] = None, hrs: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -502,7 +515,11 @@ class TrainStep:
             self._static[1].copy_(hrs)
         if isinstance(self.opt, FlatAdamW):
             self.opt.advance()
-        self.graph.replay()
+        if getattr(self, "_replay", None) is not None:
+            from . import hip
+            hip.check(hip.lib().vmg_replay_run(self._replay, 0, self._replay_ops, hip.stream_ptr()), "vmg_replay_run")
+        else:
+            self.graph.replay()
         return self._loss
 
     def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
