@@ -35,7 +35,9 @@ struct MorphK {
   int ss;             // stage stride of the pack (bytes)
 };
 
-template <int NK, int NCT>
+// EVEN: S is even -- a lane's features come in pairs that never straddle a position, so the gather reads and the scatter writes 32 bits
+// at a time (half the LDS instructions and address arithmetic of the element-wise form; S = 18 in VMG-REDS-few_levels).
+template <int NK, int NCT, bool EVEN>
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const MorphK a) {
   constexpr int COB = NCT * 16, KSB = 4 * COB * 16;  // bytes of one k-step of the pack
   constexpr int NST = (NK + 1) / 2;                  // stages (two k-steps each) of the pack
@@ -113,11 +115,24 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
     for (int ks = 0; ks < NK; ++ks) {
       bf16x8 tf;
       int p = p0[ks], s = s0[ks];
+      if constexpr (EVEN) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+        u32x4_t tw;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool in = p < ch;  // features >= Cp multiply zero weights
-        tf[j] = in ? *reinterpret_cast<const bf16*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : (bf16)0.f;
-        if (++s == S) { s = 0; ++p; }
+        for (int j = 0; j < 4; ++j) {
+          const bool in = p < ch;  // features >= Cp multiply zero weights
+          tw[j] = in ? *reinterpret_cast<const unsigned int*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : 0u;
+          s += 2;
+          if (s == S) { s = 0; ++p; }
+        }
+        tf = __builtin_bit_cast(bf16x8, tw);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool in = p < ch;  // features >= Cp multiply zero weights
+          tf[j] = in ? *reinterpret_cast<const bf16*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : (bf16)0.f;
+          if (++s == S) { s = 0; ++p; }
+        }
       }
       const char* wk = wl + (ks >> 1) * a.ss + (ks & 1) * KSB + kq * (COB * 16) + tok * 16;
 #pragma unroll
@@ -131,14 +146,29 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
     for (int ct = 0; ct < NCT; ++ct) {
       const int f0 = ct * 16 + kq * 4;
       int p = f0 / S, s = f0 - p * S;
+      if constexpr (EVEN) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (f0 + r < a.Cp) {
-          float v = acc[ct][r] + lbias[f0 + r];
-          if (a.relu) v = fmaxf(v, 0.f);
-          *reinterpret_cast<bf16*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = (bf16)(v * a.out_scale);
+        for (int r = 0; r < 4; r += 2) {
+          if (f0 + r < a.Cp) {  // (Cp is even: the pair is inside or outside together)
+            float v0 = acc[ct][r] + lbias[f0 + r], v1 = acc[ct][r + 1] + lbias[f0 + r + 1];
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            const bf16x2_t pr = {(bf16)(v0 * a.out_scale), (bf16)(v1 * a.out_scale)};
+            *reinterpret_cast<bf16x2_t*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = pr;
+          }
+          s += 2;
+          if (s == S) { s = 0; ++p; }
         }
-        if (++s == S) { s = 0; ++p; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (f0 + r < a.Cp) {
+            float v = acc[ct][r] + lbias[f0 + r];
+            if (a.relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<bf16*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = (bf16)(v * a.out_scale);
+          }
+          if (++s == S) { s = 0; ++p; }
+        }
       }
     }
     for (int idx = lane; idx < nvec; idx += 64) {
@@ -189,9 +219,10 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
   const int ncu = vmg_cu_count(vmg_current_device());
   long long nwg = cdiv64(k.ntiles, MF_WAVES);
   if (nwg > ncu) nwg = ncu;  // one workgroup per CU (the LDS holds the weights): tiles are strided over the waves
-#define MF_CASE(NK_, NCT_)                                                                                          \
-  if (nk == NK_ && nct == NCT_) {                                                                                   \
-    auto fn = morph_linear_kernel<NK_, NCT_>;                                                                       \
+#define MF_CASE(NK_, NCT_) MF_CASE2(NK_, NCT_, true) MF_CASE2(NK_, NCT_, false)
+#define MF_CASE2(NK_, NCT_, EV_)                                                                                    \
+  if (nk == NK_ && nct == NCT_ && (k.S % 2 == 0) == EV_) {                                                          \
+    auto fn = morph_linear_kernel<NK_, NCT_, EV_>;                                                                  \
     static bool attr_set[VMG_MAX_DEVICES] = {};                                                                     \
     const int dev = vmg_current_device();                                                                           \
     if (!attr_set[dev]) {                                                                                           \
@@ -208,6 +239,7 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
   MF_CASE(1, 2)   // Cp = 32
   MF_CASE(2, 4)   // Cp = 64
 #undef MF_CASE
+#undef MF_CASE2
   vmg_set_error("morphfc: Cp = %d is not instantiated (144, 112, 64, 32, 16)", Cp);
   return -1;
 }
