@@ -11,7 +11,11 @@ seg = rows[a:b]
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in seg:
     n = re.sub(r"\(anonymous namespace\)::|at::native::|_ZN12_GLOBAL__N_1\d*", "", r["Kernel_Name"])
-    n = re.sub(r"<.*", "", n)[:48] + ("  grid %s" % r.get("Grid_Size_X", r.get("Grid_Size", "")) if False else "")
+    if "elementwise" in n or "Functor" in n:  # torch: keep the functor name
+        m = re.search(r"(\w+Functor\w*|\w+_kernel_cuda|direct_copy\w*|\w+_kernel_impl\w*)<?(c10::BFloat16|float|double)?", n.split("<", 1)[1] if "<" in n else n)
+        n = "torch " + (m.group(0) if m else n[:60]) + "  [%s threads]" % r.get("Grid_Size_X", "?")
+    else:
+        n = re.sub(r"<.*", "", n)[:48]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg[n][0] += 1
     agg[n][1] += d

@@ -362,15 +362,17 @@ int launch_ltam(const LtamK& k, bool backward, hipStream_t st) {
   if (!backward) {
     const int lds = 3 * LT_PIX * RS * (int)sizeof(T) + LT_PIX * 4 + 2 * LT_PIX * 4;
     auto fn = ltam_fwd_kernel<T, D>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static bool set[VMG_MAX_DEVICES] = {};  // the attribute is per device
+    const int dev = vmg_current_device();
+    if (!set[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set[dev] = true; }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, k);
   } else {
     const int lds = 3 * LT_PIX * RS * (int)sizeof(T) + (2 * LT_PIX + 2 * LT_PIX * LT_HEADS + LT_HEADS * 256) * 4 + 2 * LT_PIX * 4;
     VMG_CHECK(lds <= 160 * 1024, "ltam_bwd: LDS request %d B exceeds 160 KiB", lds);
     auto fn = ltam_bwd_kernel<T, D>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static bool set[VMG_MAX_DEVICES] = {};  // the attribute is per device
+    const int dev = vmg_current_device();
+    if (!set[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set[dev] = true; }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, k);
   }
   VMG_LAUNCH_CHECK();
