@@ -934,6 +934,9 @@ __device__ __forceinline__ void ws_stamp(const ConvK& a, int wave, int slot) {
 #endif
 }
 
+// (Tried and dropped: the consumers storing their accumulators directly -- a lane holds 4 consecutive channels of a pixel, one 8-byte store
+// per tile, residual prefetched in the same layout -- instead of the LDS patch below: 22.6 us per launch by events instead of 21.1; the
+// 32-byte runs per pixel cost more than the patch and the item pass.)
 // The epilogue works on ITEMS = (pixel of the tile, 8 consecutive output channels): item j = pixel j / C8, channel group j % C8,
 // thread `tid` of the 448 owns items tid, tid + 448, ...  The consumers spill their accumulators to an LDS patch [128 pixels][COB]
 // fp32 (pixel stride COB*4 + 16 bytes: conflict-free 16-byte writes), then ALL seven waves turn items into 16-byte global
