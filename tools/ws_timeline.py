@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vmg_amd import hip, kernels as K
 
-N, H, W, C = 8, 64, 64, 144
+N, H, W, C = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 64, 64, 144
 x = torch.randn(N, H, W, C, device="cuda").to(torch.bfloat16)
 w = torch.randn(C, C, 3, 3, device="cuda") * (C * 9) ** -0.5
 b = torch.randn(C, device="cuda")
