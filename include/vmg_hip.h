@@ -242,6 +242,11 @@ int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, 
                       int C, float eps, void* stream);
 int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,
                       float* dw, float* db, int64_t M, int C, void* stream);
+/* the same with dx = add + LayerNorm backward (add: contiguous (M, C) in the activation dtype, or null): the gradient that reaches the
+ * normalised tensor through a skip connection (TAB: x feeds norm2 / norm3 AND the residual, models/function.py:1212-1217) is summed here
+ * instead of by a separate pass */
+int vmg_layernorm_bwd_add(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, const void* add,
+                          void* dx, float* dw, float* db, int64_t M, int C, void* stream);
 
 /* ---- UpdownkeepSampling (reference: models/layers.py:777-798): the space<->depth rearrangement fused into the LayerNorm that follows it.
  * The LayerNorm rows are GATHERED from the feature map (forward) and their gradient is scattered back (backward); no rearranged

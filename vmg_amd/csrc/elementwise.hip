@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, long long M, int C,
-                                                            const LnMap map) {
+                                                            const LnMap map, const T* __restrict__ add) {
+  // add (optional, contiguous rows): a gradient that reaches the same tensor by a skip connection; dx = add + LayerNorm backward, so the
+  // sum does not cost a pass of its own (the TAB residuals: x feeds the norm AND the residual add)
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
@@ -250,6 +252,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
           const float g = to_f32(bg[k].v[e]) * wr[k][e];
           o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
+        }
+        if (add) {
+          const VecN<T, V> av = reinterpret_cast<const VecN<T, V>*>(add + row * C)[vi];
+#pragma unroll
+          for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>(to_f32(o.v[e]) + to_f32(av.v[e]));
         }
         *reinterpret_cast<VecN<T, V>*>(dx + ln_src_elem(map, row, vi * V, C)) = o;
       }
@@ -347,7 +354,7 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
 
 template <typename T, int V>
 static int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
-                    long long M, int C, hipStream_t st, const LnMap map) {
+                    long long M, int C, hipStream_t st, const LnMap map, const void* add) {
   const int nvec = C / V;
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
@@ -355,7 +362,7 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 256 ? 256 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
   const int lds = 2 * C * 4;
   const int nv = (nvec + G - 1) / G;
-#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map)
+#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add)
 #define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
   if (G == 16) LN_LAUNCH_G(16);
   else if (G == 32) LN_LAUNCH_G(32);
@@ -419,7 +426,7 @@ extern "C" int vmg_space_depth_ln_fwd(int dtype, int mode, const void* x, const 
 }
 
 static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw,
-                       float* db, int64_t M, int C, void* stream, const LnMap map, int vmax) {
+                       float* db, int64_t M, int C, void* stream, const LnMap map, int vmax, const void* add = nullptr) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_bwd: bad dtype");
   VMG_CHECK(dy && x && mean && rstd && w && dx && dw && db && M > 0 && C > 0, "layernorm_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -427,22 +434,28 @@ static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* me
   while (v > vmax) v >>= 1;
   if (dtype == VMG_BF16) {
     switch (v) {
-      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
-      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
-      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
-      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
     }
   }
   switch (v) {
-    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
-    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
-    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map);
+    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
   }
 }
 
 extern "C" int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,
                                  void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
   return ln_bwd_impl(dtype, dy, x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{0, 0, 0, 0}, 8);
+}
+
+extern "C" int vmg_layernorm_bwd_add(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,
+                                     const void* add, void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
+  VMG_CHECK(!add || (uintptr_t)add % 16 == 0, "layernorm_bwd_add: add must be 16-byte aligned");
+  return ln_bwd_impl(dtype, dy, x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{0, 0, 0, 0}, 8, add);
 }
 
 extern "C" int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,

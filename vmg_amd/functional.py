@@ -624,6 +624,39 @@ def space_depth_layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, ep
     return y.reshape(B, T, *y.shape[1:])
 
 
+class _LayerNormSkip(_Fn):
+    """(LayerNorm(x), x): the second output is x itself, for the skip connection around the normalised branch.  Both gradients meet in
+    THIS node's backward, where the LayerNorm backward kernel adds the skip gradient on its way out (vmg_layernorm_bwd_add) -- autograd
+    would otherwise sum the two with a separate full-size pass per LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_forward(x, w, b, eps)
+        ctx.save_for_backward(x, mean, rstd, w)
+        ctx.direct = DEFERRED.direct(w, b)
+        if ctx.direct:
+            ctx.params, ctx.gen = (w, b), DEFERRED.note_params(w, b)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, mean, rstd, w = ctx.saved_tensors
+        into = tuple(DEFERRED.grad_of(p) for p in ctx.params) if ctx.direct else None
+        if dy is None:  # (the normalised branch is unused)
+            return dskip, None, None, None
+        dx, dw, db = K.layernorm_backward(dy, x, mean, rstd, w, into=into, add=dskip)
+        if ctx.direct:
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return dx, None, None, None
+        return dx, dw, db, None
+
+
+def layer_norm_skip(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """(nn.LayerNorm(x), x) with the skip gradient summed inside the LayerNorm backward kernel."""
+    return _LayerNormSkip.apply(x, w, b, eps)
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """nn.LayerNorm over the last (channel) dimension."""
     return _LayerNorm.apply(x, w, b, eps)

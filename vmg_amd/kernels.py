@@ -368,14 +368,23 @@ def _grad_pair(C: int, device, into):
     return dw, db
 
 
-def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None):
-    """into = (dw, db): the kernel's atomic sums are ADDED to these buffers (param.grad) instead of to fresh zero tensors."""
-    hip.require_cuda(dy, x, mean, rstd, w)
+def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None, add=None):
+    """into = (dw, db): the kernel's atomic sums are ADDED to these buffers (param.grad) instead of to fresh zero tensors.
+    add: a gradient of x's shape that is summed into dx by the kernel (the skip-connection gradient)."""
+    hip.require_cuda(dy, x, mean, rstd, w, add)
     C = x.shape[-1]
     M = x.numel() // C
     dy = dy.contiguous()
     dx = torch.empty_like(x)
     dw, db = _grad_pair(C, x.device, into)
+    if add is not None:
+        if add.shape != x.shape or add.dtype != x.dtype:
+            raise HipError("layernorm_backward: add must have x's shape and dtype")
+        add = add.contiguous()
+        hip.check(hip.lib().vmg_layernorm_bwd_add(hip.dtype_code(x.dtype), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(),
+                                                  add.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
+                  "vmg_layernorm_bwd_add")
+        return dx, dw, db
     hip.check(hip.lib().vmg_layernorm_bwd(hip.dtype_code(x.dtype), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                           w.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C, hip.stream_ptr()),
               "vmg_layernorm_bwd")

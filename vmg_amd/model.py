@@ -280,12 +280,14 @@ class TAB(nn.Module):
     def forward(self, x):
         s = self.spatial_scale
         dp = self.drop_prob > 0.0 and self.training
-        y = self.spatial_mixing(lnorm(self.norm2, x))
-        x = FH.residual_drop_path(x, y, self.drop_prob, self.training, s)  # one pass: mask, scale and add
-        n3 = lnorm(self.norm3, x)
+        # x feeds the norm AND the residual: layer_norm_skip hands x back so that both gradients meet in the LayerNorm backward kernel
+        n2, xs = FH.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        y = self.spatial_mixing(n2)
+        x = FH.residual_drop_path(xs, y, self.drop_prob, self.training, s)  # one pass: mask, scale and add
+        n3, xs = FH.layer_norm_skip(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         if isinstance(self.channel_mixing, Mlp_cnn) and not dp and s == 1.0:
-            return self.channel_mixing(n3, res=x)  # residual fused in the Linear epilogue
-        return FH.residual_drop_path(x, self.channel_mixing(n3), self.drop_prob, self.training, s)
+            return self.channel_mixing(n3, res=xs)  # residual fused in the Linear epilogue
+        return FH.residual_drop_path(xs, self.channel_mixing(n3), self.drop_prob, self.training, s)
 
 
 # ---------------------------------------------------------------------------------------------------------
