@@ -359,7 +359,7 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
-  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 256 ? 256 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
+  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 512 ? 512 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
   const int lds = 2 * C * 4;
   const int nv = (nvec + G - 1) / G;
 #define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add)
