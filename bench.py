@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
                     "HIP-event roofline needs eager launches, so eager is the default)")
+    ap.add_argument("--recompute", action="store_true", help="VMG(recompute_chains=True): the recurrent residual chains keep only their inputs and "
+                    "are re-run in the backward (SURVEY 8f-4); prints the peak device memory next to the throughput")
     ap.add_argument("--replay", action="store_true", help="with --graph: re-issue the captured launches with plain hipLaunchKernel calls "
                     "(vmg_replay_run) instead of hipGraphLaunch -- a measurement of the launch path only (+1 %), see TrainStep.capture")
     args = ap.parse_args()
@@ -158,6 +160,7 @@ def main():
     wl = WORKLOADS[args.workload]
     B, Tn, S = wl["batch"], wl["frames"], wl["size"]
     model = build_model(device, wl)
+    model.recompute_chains = bool(args.recompute)
     if args.workload == "infer":
         lrs = synthetic_clip(1, Tn, 180, 320, seed=7 + rank, device=device)
 
@@ -257,6 +260,8 @@ def main():
     }
     if train:
         line["config"]["loss"] = float(loss)
+        line["config"]["recompute_chains"] = bool(args.recompute)
+        line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     if args.workload == "train":
         line["config"]["model_tflops"] = round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2)
     if rank == 0:

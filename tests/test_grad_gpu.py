@@ -128,3 +128,29 @@ def test_bf16_whole_model_gradients_few_levels():
     print(f"bf16 few_levels gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}")
     assert cos >= 0.995, cos
     assert worst[0] <= 0.12, worst
+
+
+def test_recompute_chains_gives_the_same_gradients():
+    """VMG(recompute_chains=True): the recurrent residual chains keep only their inputs and are re-run in the backward.
+    Output and every parameter gradient must equal the run that saved the intermediates up to the run-to-run noise of the float-atomic
+    reductions (pooled sums, fp32 weight gradients): 1e-5 on the output, 1e-3 of each gradient's scale (floor: 1e-3 of the largest gradient)."""
+    from oracle import cases as C
+    from tests.util import build_product
+    case = C.CASES["vmg_tiny_few"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"].cuda()
+    res = []
+    for rc in (False, True):
+        m = build_product(case["cfg"], torch.float32)
+        m.load_state_dict(sd)
+        m.train()
+        m.recompute_chains = rc
+        out = m(x)
+        out.square().mean().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert float((a - b).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-3 * gmax), k

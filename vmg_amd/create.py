@@ -39,4 +39,5 @@ def create_model(config):
         kw[vk] = v
     cd = config.get("compute_dtype", "float32") if hasattr(config, "get") else "float32"
     kw["compute_dtype"] = {"float32": torch.float32, "bfloat16": torch.bfloat16, None: torch.float32}[cd]
+    kw["recompute_chains"] = bool(config.get("recompute_chains", False)) if hasattr(config, "get") else False  # optional: activation recompute
     return VMG(image_size=image_size, is_train=config["is_train"], **kw)

@@ -229,7 +229,8 @@ def _parr(ts):
 
 
 def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: torch.Tensor, slope0: float, deep0: int, pw1: Sequence[PackedConv],
-                           b1: Sequence[torch.Tensor], pw2: Sequence[PackedConv], b2: Sequence[torch.Tensor], r_scaling: float, deep: int):
+                           b1: Sequence[torch.Tensor], pw2: Sequence[PackedConv], b2: Sequence[torch.Tensor], r_scaling: float, deep: int,
+                           own_output: bool = False):
     """ResidualBlocksWithInputConv forward as ONE C call (vmg_resblock_chain_fwd).  Returns (ys, ts): nblk + 1 block outputs and nblk
     ReLU outputs, all (N, H, W, C)."""
     x0 = srcs[0]
@@ -247,6 +248,8 @@ def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: to
             raise HipError("resblock_chain: biases must be contiguous fp32 of length C")
     blk = torch.empty((2 * nblk + 1, N, H, W, C), dtype=dt, device=x0.device).unbind(0)  # ONE allocation: 31 torch.empty calls cost 0.1 ms of host time per chain
     ys, ts = list(blk[:nblk + 1]), list(blk[nblk + 1:])
+    if own_output:  # the chain's output in its own allocation: the caller drops the intermediates (activation recompute)
+        ys[-1] = torch.empty((N, H, W, C), dtype=dt, device=x0.device)
     d = hip.ChainDesc()
     d.dtype, d.N, d.H, d.W, d.C, d.nblk, d.nsrc = hip.dtype_code(dt), N, H, W, C, nblk, len(srcs)
     for i, s in enumerate(srcs):

@@ -308,11 +308,12 @@ class ResidualBlocksWithInputConv(nn.Module):
         super().__init__()
         self.main = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1), nn.LeakyReLU(0.1),
                                   nn.Sequential(*[ResidualBlockNoBN0(out_channels, r_scaling) for _ in range(num_blocks)]))
+        self.recompute = False  # VMG(recompute_chains=True): drop the 2 * num_blocks intermediates, rebuild them in the backward
 
     def forward(self, srcs: Sequence[torch.Tensor]):
         blocks = list(self.main[2])
         r = blocks[0].res_scale if blocks else 1.0
-        return FH.residual_chain([t.contiguous() for t in srcs], self.main[0], blocks, r)
+        return FH.residual_chain([t.contiguous() for t in srcs], self.main[0], blocks, r, recompute=self.recompute and torch.is_grad_enabled())
 
 
 class LTAM_multi_head(nn.Module):
@@ -580,7 +581,7 @@ class VMG(nn.Module):
                  non_linear=True, gating=True, symm=True, symm_act=nn.Tanh, relu_scale=True, relu_scale_norm=False,
                  ffn_type='vanilla', mixer_type=['mbconv', 'mbconv', 'mlps', 'mlps'], mixer_n=[2, 3, None, None], r_scaling=1.,
                  chunk_ratios=[1 / 4, 1 / 4, 3 / 16, 1 / 8], traj_mode='wins', twins=[2, 2], traj_scale=True, traj_refine=None,
-                 m_scaling=1., if_local_fuse=False, channel_mixer='vanilla', compute_dtype=torch.float32):
+                 m_scaling=1., if_local_fuse=False, channel_mixer='vanilla', compute_dtype=torch.float32, recompute_chains=False):
         super().__init__()
         # --- options the hand-written path implements (every self-consistent shipped config)
         if not (ltam and retention_decay and non_linear and gating and symm and relu_scale) or relu_scale_norm or if_concat:
@@ -602,6 +603,7 @@ class VMG(nn.Module):
         self.if_print = if_print
         self.init_H, self.init_W = image_size
         self.compute_dtype = compute_dtype
+        self.recompute_chains = bool(recompute_chains)  # the recurrent residual chains keep their inputs only and are re-run in the backward
         self.spynet = SPyNet(spynet_pretrained) if spynet_pretrained is not None else None
 
         enc_dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths[:self.num_enc_layers]))]
@@ -726,6 +728,11 @@ class VMG(nn.Module):
         if self.spynet is None:
             raise HipError("VMG.spynet is None: the trajectory modules need optical flow (the reference crashes here too, "
                            "models/trajectory.py:329); construct with spynet_pretrained or attach SPyNet(None)")
+        if getattr(self, "_recompute_applied", None) != self.recompute_chains:
+            for m in self.modules():
+                if isinstance(m, ResidualBlocksWithInputConv):
+                    m.recompute = self.recompute_chains
+            self._recompute_applied = self.recompute_chains
         if torch.is_grad_enabled():
             FH.DEFERRED.begin_forward()  # per-pass use counts of the deferred weight gradients (functional._DeferredWgrad)
         # the kernels take fp32 / the module's compute dtype; an enclosing torch.autocast (tools/Trainer.py:132-143) must not
