@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       for (int k = 0; k < C::DY_NV; ++k) {
         bool ok; int c;
         const char* src = dy_src(k, ok, c);
-        rdy[k] = *reinterpret_cast<const uint4*>((ok && c + C::VPL <= a.Cout) ? src : zsrc);
+        rdy[k] = *reinterpret_cast<const uint4*>((ok && c < a.Cout) ? src : zsrc);  // (a vector that starts inside the channels ends inside the pixel stride: channels past Cout are computed and dropped)
       }
     } else {
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
       for (int k = 0; k < C::X_NV; ++k) {
         bool ok; int c;
         const char* src = x_src(k, ok, c);
-        rx[k] = *reinterpret_cast<const uint4*>((ok && c + C::VPL <= a.Cin) ? src : zsrc);
+        rx[k] = *reinterpret_cast<const uint4*>((ok && c < a.Cin) ? src : zsrc);
       }
     } else {
 #pragma unroll
@@ -403,8 +403,11 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
   const int es = dtype == VMG_BF16 ? 2 : 4, vpl = 16 / es;
   WgradK k;
   memset(&k, 0, sizeof(k));
-  k.vec_x = (x_ps % vpl == 0) && (Cin % vpl == 0);
-  k.vec_dy = (dy_ps % vpl == 0) && (Cout % vpl == 0);
+  // 16-byte vector loads need a pixel stride that is a multiple of the vector (then a vector that starts inside the channel range ends
+  // inside the pixel's stride: a zero-padded or wider tensor behind a channel slice, e.g. the 3-channel output gradient of conv_last
+  // padded to 8) and aligned bases; channel counts need not be multiples of 8
+  k.vec_x = (x_ps % vpl == 0);
+  k.vec_dy = (dy_ps % vpl == 0);
   for (int p = 0; p < npairs; ++p) {
     VMG_CHECK(x[p] && dy[p], "conv_wgrad: null pointer in pair %d", p);
     k.x[p] = (const char*)x[p];
@@ -428,6 +431,11 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
       k.M = ws_bytes / 4;  // (launch_wgrad reads the workspace size from here and restores M)
     }
     return dtype == VMG_BF16 ? launch_wgrad<bf16, 7, 1, 1, 1>(k, st) : launch_wgrad<float, 7, 1, 1, 1>(k, st);
+  }
+  if (dtype == VMG_BF16 && ks == 3 && Cout <= 16) {  // (conv_last: 64 -> 3 on 1.8 M pixels; 64 input channels per workgroup: whole 128-byte pixel rows of X)
+    // (slab partials + ordered reduce instead of the float atomics were tried here: the kernel stays at 470 us -- it is bound by its
+    //  serialised loads, like the 7x7 case before conv_wgrad7_kernel -- and the 1 024-slab reduce adds 250 us)
+    return Cin >= 64 ? launch_wgrad<bf16, 3, 1, 4>(k, st) : launch_wgrad<bf16, 3, 1, 1>(k, st);
   }
   if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
   return ks == 3 ? launch_wgrad<float, 3, 3, 1>(k, st) : launch_wgrad<float, 1, 3, 3>(k, st);
@@ -1298,7 +1306,7 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
   // zero-padded input of the 3-channel stem conv, a slice of a wider tensor: the extra channels are computed and dropped)
   const int cin8 = (Cin + 7) & ~7, cout8 = (Cout + 7) & ~7;
   bool ok = ws && dtype == VMG_BF16 && ks == 3 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && (x_ps % 8 == 0) && (dy_ps % 8 == 0) &&
-            x_ps >= cin8 && dy_ps >= cout8;
+            x_ps >= cin8 && dy_ps >= cout8 && Cout > 16;  // (Cout <= 16: the 144-channel tile would be 9/10 padding; the 16-channel tile of the v1 kernel)
   for (int p = 0; ok && p < npairs; ++p) ok = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 16 == 0);
   if (!ok) return wgrad_impl(dtype, ks, npairs, x, dy, N, H, W, x_ps, Cin, dy_ps, Cout, dW, I_total, o0, i0, db, scale, stream, (float*)ws, ws_bytes);
   VMG_CHECK(N > 0 && H > 0 && W > 0 && dW && x_ps >= Cin && dy_ps >= Cout && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0, "conv_wgrad: bad arguments");

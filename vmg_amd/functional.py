@@ -447,10 +447,12 @@ class _Conv2d(_Fn):
             else:
                 d_srcs.append(None)
             off += c
+        # the weight gradient reads the zero-padded copy through a channel slice (pixel stride 8): 16-byte vector loads instead of O scalar ones
+        dpre_w = dpre_p[..., :O] if dpre_p.shape[-1] != O else dpre
         if ctx.defer:
-            DEFERRED.add(weight, ctx.bias_ref, list(srcs_p), ctx.src_ch, dpre, ks, N, H, W, gen=ctx.gen)
+            DEFERRED.add(weight, ctx.bias_ref, list(srcs_p), ctx.src_ch, dpre_w, ks, N, H, W, gen=ctx.gen)
         elif ctx.needs_input_grad[0]:
-            d_w, d_b = _wgrad_now(weight, ctx.has_bias and ctx.needs_input_grad[1], list(srcs_p), ctx.src_ch, dpre, ks, N, H, W)
+            d_w, d_b = _wgrad_now(weight, ctx.has_bias and ctx.needs_input_grad[1], list(srcs_p), ctx.src_ch, dpre_w, ks, N, H, W)
             if weight.dim() == 2:
                 d_w = d_w.reshape(weight.shape)
         elif ctx.has_bias and ctx.needs_input_grad[1]:
