@@ -158,3 +158,28 @@ def test_se_mlp_fwd_bwd_matches_torch(case):
     for g, w, name, sc in zip(got, grads, ("dm", "dw1", "db1", "dw2", "db2"), (0.25, 1, 1, 1, 1)):
         err = float((g.cpu() - sc * w).abs().max())
         assert err <= 1e-5 * max(1.0, float(w.abs().max())), f"{name}: {err}"
+
+
+def test_drop_path_plan_matches_per_call_semantics():
+    """functional._DropPlan: the second forward pass draws all DropPath masks at once.  Every (sample, call) coefficient must be 0 or
+    scale / keep (timm's DropPath), constant over channels and pixels; a call that deviates from the recorded sequence falls back."""
+    from vmg_amd import functional as FH
+    B, T, H, W, C = 6, 2, 4, 4, 16
+    res = torch.zeros(B, T, H, W, C, device="cuda", dtype=torch.bfloat16)
+    y = torch.ones(B, T, H, W, C, device="cuda", dtype=torch.bfloat16)
+    calls = [(0.25, 1.0), (0.5, 0.5), (0.1, 1.0)]
+    for rnd in range(3):
+        FH.DROP.begin(res.device, True)
+        for p, s in calls:
+            out = FH.residual_drop_path(res, y, p, True, s).float()
+            per = out.reshape(B, -1)
+            assert bool((per == per[:, :1]).all())  # one coefficient per sample
+            v = per[:, 0]
+            want = s / (1.0 - p)
+            assert bool(((v == 0) | ((v - want).abs() <= 1e-2 * want)).all()), (rnd, p, s, v)
+        if rnd >= 1:
+            assert FH.DROP.plan is not None and FH.DROP.idx == len(calls)
+    FH.DROP.begin(res.device, True)
+    FH.residual_drop_path(res, y, 0.3, True, 1.0)  # not the recorded first call: per-call path, still valid
+    assert FH.DROP.g is None
+    FH.DROP.begin(res.device, False)

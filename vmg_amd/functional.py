@@ -853,15 +853,60 @@ class _ResidualDropPath(_Fn):
     add; the backward is one multiply (d_res is dy itself)."""
 
     @staticmethod
-    def forward(ctx, res, y, g):
+    def forward(ctx, res, y, g, gb=None):
         out = K.tab_elementwise(K.OP_CA_FWD, y.contiguous(), res.contiguous(), coef=g, s=1.0, G=g.shape[0])
-        ctx.save_for_backward(g.reshape((g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)).to(y.dtype))  # (B, C): cast once, here
+        if gb is None:
+            gb = g.to(y.dtype)  # (B, C): cast once, here
+        ctx.save_for_backward(gb.reshape((g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)))
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (gb,) = ctx.saved_tensors
-        return dy, dy * gb, None
+        return dy, dy * gb, None, None
+
+
+class _DropPlan:
+    """The DropPath coefficients of a whole forward pass from one handful of launches.  Every residual_drop_path call used to cost five
+    tiny kernels (bernoulli_, div_, mul, expand + contiguous, a cast for the backward) -- ~100 launches per train step.  The calls of
+    one forward pass (batch, channels, keep probability, scale) are recorded; the NEXT pass, if it makes the same calls in the same
+    order, draws all masks at once (rand < keep, / keep, * scale: timm's DropPath per call, from one generator draw).  Any
+    deviation from the recorded sequence falls back to the per-call path."""
+
+    def __init__(self):
+        self.rec, self.plan, self.g, self.gb, self.idx, self.consts = [], None, None, None, 0, {}
+
+    def begin(self, device, active: bool):
+        rec, self.rec = self.rec, []
+        self.idx, self.g, self.gb, self.plan = 0, None, None, None
+        if not active or not rec or any(r[:2] != rec[0][:2] for r in rec) or any(r[2] <= 0.0 for r in rec):
+            return
+        key = (tuple(rec), str(device))
+        c = self.consts.get(key)
+        if c is None:
+            keep = torch.tensor([r[2] for r in rec], dtype=torch.float32, device=device).reshape(-1, 1, 1)
+            mult = torch.tensor([r[3] / r[2] for r in rec], dtype=torch.float32, device=device).reshape(-1, 1, 1)
+            c = self.consts[key] = (keep, mult)
+            if len(self.consts) > 8:
+                self.consts.pop(next(iter(self.consts)))
+        B, C = rec[0][:2]
+        u = torch.rand(len(rec), B, 1, device=device)
+        self.g = ((u < c[0]).to(torch.float32) * c[1]).expand(len(rec), B, C).contiguous()
+        self.plan = rec
+
+    def take(self, B, C, keep, scale, dtype):
+        i = self.idx
+        self.idx += 1
+        self.rec.append((B, C, float(keep), float(scale)))
+        if self.g is None or i >= len(self.plan) or self.plan[i] != self.rec[-1]:
+            self.g = None  # out of step with the recorded sequence: per-call path for the rest of this pass
+            return None, None
+        if self.gb is None or self.gb.dtype != dtype:
+            self.gb = self.g.to(dtype)
+        return self.g[i], self.gb[i]
+
+
+DROP = _DropPlan()
 
 
 def residual_drop_path(res: torch.Tensor, y: torch.Tensor, p: float, training: bool, scale: float = 1.0) -> torch.Tensor:
@@ -871,6 +916,9 @@ def residual_drop_path(res: torch.Tensor, y: torch.Tensor, p: float, training: b
     B, C = y.shape[0], y.shape[-1]
     if p > 0.0 and training:
         keep = 1.0 - p
+        g, gb = DROP.take(B, C, keep, scale, y.dtype)
+        if g is not None:
+            return _ResidualDropPath.apply(res, y, g, gb)
         mask = torch.empty(B, 1, dtype=torch.float32, device=y.device).bernoulli_(keep)
         if keep > 0.0:
             mask.div_(keep)

@@ -733,6 +733,7 @@ class VMG(nn.Module):
                 if isinstance(m, ResidualBlocksWithInputConv):
                     m.recompute = self.recompute_chains
             self._recompute_applied = self.recompute_chains
+        FH.DROP.begin(x.device, self.training)  # the DropPath masks of this pass in one draw (functional._DropPlan)
         if torch.is_grad_enabled():
             FH.DEFERRED.begin_forward()  # per-pass use counts of the deferred weight gradients (functional._DeferredWgrad)
         # the kernels take fp32 / the module's compute dtype; an enclosing torch.autocast (tools/Trainer.py:132-143) must not
