@@ -495,6 +495,38 @@ def test_conv7x7_wgrad_slab_kernel(shape):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)  # slabs are summed in a fixed order
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 70, 64, 3), (2, 16, 32, 16, 16), (5, 9, 33, 24, 2), (1, 64, 64, 64, 8)])
+def test_conv3x3_small_cout_wgrad_kernel(shape):
+    """3x3 weight gradient with <= 16 output channels (conv_last: 64 -> 3) on the three-wave instance of the tap-row kernel: row blocks
+    and column segments that do not divide the image, two pairs, a scale, accumulation, and a 3-channel dY that is a slice of a
+    zero-padded 8-channel buffer (what the model's backward hands over)."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co = shape
+    dt = torch.bfloat16
+    xs = [_q(R.seeded((N, H, W, Ci), 171 + i), dt) for i in range(2)]
+    dys = [_q(R.seeded((N, H, W, Co), 181 + i), dt) for i in range(2)]
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    loss = sum((O.conv_nhwc(x, w, b, 1) * dy).sum() for x, dy in zip(xs, dys))
+    gw, gb = torch.autograd.grad(loss, (w, b))
+    dW0, db0 = R.seeded((Co, Ci, 3, 3), 191), R.seeded((Co,), 192)
+
+    def padded(d):
+        buf = torch.full((N, H, W, (Co + 7) // 8 * 8), 3.0, dtype=dt, device="cuda")  # (the pad channels are computed and dropped)
+        buf[..., :Co] = d.cuda().to(dt)
+        return buf[..., :Co]
+
+    outs = []
+    for _ in range(2):
+        dW, db = dW0.cuda(), db0.cuda()
+        K.conv_wgrad_batched([x.cuda().to(dt) for x in xs], [padded(d) for d in dys], dW, db, 3, N, H, W, scale=0.5)
+        outs.append((dW, db))
+    wantW, wantb = dW0 + 0.5 * gw, db0 + 0.5 * gb
+    assert float((outs[0][0].cpu() - wantW).abs().max()) <= 2e-3 * max(1.0, float(wantW.abs().max()))
+    assert float((outs[0][1].cpu() - wantb).abs().max()) <= 2e-3 * max(1.0, float(wantb.abs().max()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])  # slabs are summed in a fixed order
+
+
 def test_repack_all_equals_individual_packs():
     """The one-launch repack plan (vmg_pack_entry / vmg_pack_run) rebuilds exactly the bytes the single pack calls produce: forward and
     data-gradient packs, both layouts, fp32 and bf16, 1x1 / 3x3 / 7x7, a channel slice, after an 'optimizer step' that rewrote the weights."""

@@ -433,8 +433,8 @@ static int wgrad_impl(int dtype, int ks, int npairs, const void* const* x, const
     return dtype == VMG_BF16 ? launch_wgrad<bf16, 7, 1, 1, 1>(k, st) : launch_wgrad<float, 7, 1, 1, 1>(k, st);
   }
   if (dtype == VMG_BF16 && ks == 3 && Cout <= 16) {  // (conv_last: 64 -> 3 on 1.8 M pixels; 64 input channels per workgroup: whole 128-byte pixel rows of X)
-    // (slab partials + ordered reduce instead of the float atomics were tried here: the kernel stays at 470 us -- it is bound by its
-    //  serialised loads, like the 7x7 case before conv_wgrad7_kernel -- and the 1 024-slab reduce adds 250 us)
+    // (only without a workspace: vmg_conv_wgrad_batched_ws sends this shape to the three-wave instance of conv_wgrad7_kernel, 122 us
+    //  instead of 470-560 here, where ~650 address instructions per K unit and one wave per SIMD leave the loads exposed)
     return Cin >= 64 ? launch_wgrad<bf16, 3, 1, 4>(k, st) : launch_wgrad<bf16, 3, 1, 1>(k, st);
   }
   if (dtype == VMG_BF16) return ks == 3 ? launch_wgrad<bf16, 3, 3, 1>(k, st) : launch_wgrad<bf16, 1, 3, 3>(k, st);
@@ -950,18 +950,25 @@ __global__ __launch_bounds__(256) void linear_wgrad2_reduce_kernel(const float* 
 // (co, ci, tap) lives in exactly one wave: no reduction inside the workgroup; slab partials in the accumulators' native layout
 // (coalesced float4 stores) and a second kernel sums the slabs in a fixed order (deterministic) into dW / db.  The bias
 // gradient is one more MFMA per co tile against a ones vector on wave 0 of ci block 0.
-constexpr int W7_R = 4, W7_THREADS = 448, W7_XW = 38, W7_XR = W7_R + 6;
-constexpr int W7_X_RS = 48;                          // LDS pixel stride of the X tile: 16 channels + 16 bytes (conflict-free transposed reads)
-constexpr int W7_XVEC = W7_XR * W7_XW * 2;           // 760 16-byte vectors
-constexpr int W7_NX = (W7_XVEC + W7_THREADS - 1) / W7_THREADS;
-constexpr int W7_X_BYTES = (W7_NX * W7_THREADS / 2) * W7_X_RS;  // room for every thread's NX vectors: the staging stores are unconditional
-template <int CT>
+// The same kernel with KS = 3 (three waves, 8 rows per unit) takes the 3x3 convs with <= 16 output channels (conv_last: 64 -> 3 on the 1.8 M
+// HR pixels of a batch), where the 144-channel tile of conv_wgrad3_kernel would be 9/10 padding.
+constexpr int W7_X_RS = 48;  // LDS pixel stride of the X tile: 16 channels + 16 bytes (conflict-free transposed reads)
+template <int KS>
+struct W7Geo {
+  static constexpr int R = KS == 7 ? 4 : 8;  // image rows per K unit (3x3 with 4 rows and 768 workgroups: 140 us instead of 122 on conv_last)
+  static constexpr int THREADS = KS * 64, XW = 32 + KS - 1, XR = R + KS - 1;
+  static constexpr int XVEC = XR * XW * 2;  // 16-byte vectors of the X tile (7x7: 760)
+  static constexpr int NX = (XVEC + THREADS - 1) / THREADS;
+  static constexpr int X_BYTES = ((NX * THREADS + 1) / 2) * W7_X_RS;  // room for every thread's NX vectors: the staging stores are unconditional
+};
+template <int CT, int KS = 7>
 struct W7Cfg {
-  static constexpr int DY_RS = CT * 32 + 16, DYVEC = W7_R * 32 * CT * 2;
-  static constexpr int NX = W7_NX, NDY = (DYVEC + W7_THREADS - 1) / W7_THREADS;
-  static constexpr int DY_BYTES = ((NDY * W7_THREADS + CT * 2 - 1) / (CT * 2)) * DY_RS;  // (same: room for the padding vectors)
-  static constexpr int BUF = (W7_X_BYTES + DY_BYTES + 15) & ~15;
-  static constexpr int WG_FLOATS = (49 * CT + CT) * 256;  // tiles [ky][ct][kx], then the CT bias tiles
+  using G = W7Geo<KS>;
+  static constexpr int DY_RS = CT * 32 + 16, DYVEC = G::R * 32 * CT * 2;
+  static constexpr int NX = G::NX, NDY = (DYVEC + G::THREADS - 1) / G::THREADS;
+  static constexpr int DY_BYTES = ((NDY * G::THREADS + CT * 2 - 1) / (CT * 2)) * DY_RS;  // (same: room for the padding vectors)
+  static constexpr int BUF = (G::X_BYTES + DY_BYTES + 15) & ~15;
+  static constexpr int WG_FLOATS = (KS * KS * CT + CT) * 256;  // tiles [ky][ct][kx], then the CT bias tiles
 };
 
 struct Wgrad7K {
@@ -979,9 +986,11 @@ struct Wgrad7K {
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-template <int CT>
-__global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a) {
-  using C = W7Cfg<CT>;
+template <int CT, int KS>
+__global__ __launch_bounds__(W7Geo<KS>::THREADS) void conv_wgrad7_kernel(const Wgrad7K a) {
+  using C = W7Cfg<CT, KS>;
+  using G = W7Geo<KS>;
+  constexpr int W7_THREADS = G::THREADS, W7_XW = G::XW, W7_XVEC = G::XVEC, W7_X_BYTES = G::X_BYTES, W7_RU = G::R, HALO = KS / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int ky = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -991,12 +1000,12 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
   const bool do_bias = a.has_bias && blk.x == 0 && ky == 0;
   const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
 
-  f32x4 acc[CT][7], accb[CT];
+  f32x4 acc[CT][KS], accb[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     accb[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) acc[ct][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kx = 0; kx < KS; ++kx) acc[ct][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const __bf16 one = (__bf16)1.0f;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
     const int seg = u % a.SEG;
     u /= a.SEG;
     const int hb = u % a.HB, n = u / a.HB;
-    const int y0 = hb * W7_R, x0 = seg * 32;
+    const int y0 = hb * W7_RU, x0 = seg * 32;
     const char* xb = a.x[pair];
     const char* db_ = a.dy[pair];
 #pragma unroll
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
       const int idx = tid + k * W7_THREADS;
       const int pp = idx >> 1, v = idx & 1;
       const int r = pp / W7_XW, col = pp - r * W7_XW;
-      const int yy = y0 + r - 3, xx = x0 + col - 3, c = ib + v * 8;
+      const int yy = y0 + r - HALO, xx = x0 + col - HALO, c = ib + v * 8;
       const bool ok = idx < W7_XVEC && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && c + 8 <= a.Cin;
       const long long off = ((((long long)n * a.H + yy) * a.W + xx) * a.x_ps + c) * 2;
       rx[k] = *reinterpret_cast<const u32x4*>(ok ? xb + off : zsrc);
@@ -1027,7 +1036,7 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
         const int idx = tid + k * W7_THREADS;
         const int pp = idx / (CT * 2), v = idx - pp * (CT * 2);
         const int rr = pp >> 5, col = pp & 31;
-        const bool ok = idx < C::DYVEC && y0 + rr < a.H && x0 + col < a.W && v * 8 + 8 <= a.Cout;
+        const bool ok = idx < C::DYVEC && y0 + rr < a.H && x0 + col < a.W && v * 8 < a.Cout;  // (a vector that starts inside the channels ends inside the pixel stride)
         const long long off = ((((long long)n * a.H + y0 + rr) * a.W + x0 + col) * a.dy_ps + v * 8) * 2;
         rdy[k] = *reinterpret_cast<const u32x4*>(ok ? db_ + off : zsrc);
       }
@@ -1070,13 +1079,13 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
     const char* xt = buf;
     const char* dyt = buf + W7_X_BYTES;
 #pragma unroll
-    for (int rr = 0; rr < W7_R; ++rr) {
+    for (int rr = 0; rr < W7_RU; ++rr) {
       bf16x8 af[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) af[ct] = tr_frag(dyt, C::DY_RS, rr * 32, ct * 16, lane);
       const char* xrow = xt + (rr + ky) * (W7_XW * W7_X_RS);
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
+      for (int kx = 0; kx < KS; ++kx) {
         const bf16x8 bfg = tr_frag(xrow, W7_X_RS, kx, 0, lane);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfg, acc[ct][kx], 0, 0, 0);
@@ -1093,19 +1102,19 @@ __global__ __launch_bounds__(W7_THREADS) void conv_wgrad7_kernel(const Wgrad7K a
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx)
-      *reinterpret_cast<f32x4*>(sl + (((ky * CT + ct) * 7 + kx) * 64 + lane) * 4) = acc[ct][kx];
+    for (int kx = 0; kx < KS; ++kx)
+      *reinterpret_cast<f32x4*>(sl + (((ky * CT + ct) * KS + kx) * 64 + lane) * 4) = acc[ct][kx];
   if (ky == 0) {  // (written by every ci block so that the reduce kernel never reads uninitialised memory)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<f32x4*>(sl + ((49 * CT + ct) * 64 + lane) * 4) = accb[ct];
+    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<f32x4*>(sl + ((KS * KS * CT + ct) * 64 + lane) * 4) = accb[ct];
   }
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad7_reduce_kernel(const float* __restrict__ slab, int S, int gx, int CT, int Cin, int Cout,
+__global__ __launch_bounds__(256) void conv_wgrad7_reduce_kernel(const float* __restrict__ slab, int S, int gx, int CT, int KS, int Cin, int Cout,
                                                                  float* __restrict__ dW, int I_total, int o0, int i0,
                                                                  float* __restrict__ db, float scale) {
   __shared__ float red[256];
-  const int wgf = (49 * CT + CT) * 256;
+  const int KK = KS * KS, wgf = (KK * CT + CT) * 256;
   const long long per_s = (long long)gx * wgf;
   for (long long e0 = blockIdx.x * 64LL; e0 < per_s; e0 += (long long)gridDim.x * 64) {
     const long long i = e0 + (threadIdx.x & 63);
@@ -1115,20 +1124,20 @@ __global__ __launch_bounds__(256) void conv_wgrad7_reduce_kernel(const float* __
     const int e = (int)(i - (long long)ciblk * wgf);
     const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
     const int g = lane >> 4, l15 = lane & 15;
-    if (tile < 49 * CT) {
-      const int kx = tile % 7, ct = (tile / 7) % CT, ky = tile / (7 * CT);
+    if (tile < KK * CT) {
+      const int kx = tile % KS, ct = (tile / KS) % CT, ky = tile / (KS * CT);
       const int co = ct * 16 + 4 * g + r, ci = ciblk * 16 + l15;
-      if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 49 + ky * 7 + kx] += sum * scale;
+      if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * KK + ky * KS + kx] += sum * scale;
     } else if (db && ciblk == 0 && l15 == 0) {
-      const int co = (tile - 49 * CT) * 16 + 4 * g + r;
+      const int co = (tile - KK * CT) * 16 + 4 * g + r;
       if (co < Cout) db[o0 + co] += sum * scale;
     }
   }
 }
 
-template <int CT>
+template <int CT, int KS = 7>
 int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, float scale, int64_t ws_bytes, hipStream_t st) {
-  using C = W7Cfg<CT>;
+  using C = W7Cfg<CT, KS>;
   const int gx = cdiv(k.Cin, 16);
   long long S = 512 / gx;            // ~two rounds of workgroups over the 256 CUs
   if (S > k.U / 2) S = k.U / 2;      // >= 2 units per workgroup
@@ -1137,18 +1146,18 @@ int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, 
   if (S < 1) S = 1;
   if (cap < 1) return 1;  // (workspace too small: the caller falls back)
   k.S = (int)S; k.gx = gx;
-  auto fn = conv_wgrad7_kernel<CT>;
+  auto fn = conv_wgrad7_kernel<CT, KS>;
   static bool attr7[VMG_MAX_DEVICES] = {};  // per instantiation and device
   const int dev = vmg_current_device();
   if (!attr7[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::BUF);
     attr7[dev] = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)(gx * S)), dim3(W7_THREADS), 2 * C::BUF, st, k);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(gx * S)), dim3(W7Geo<KS>::THREADS), 2 * C::BUF, st, k);
   VMG_LAUNCH_CHECK();
   const long long per_s = (long long)gx * C::WG_FLOATS;
   const int rb = (int)(cdiv64(per_s, 64) > 8192 ? 8192 : cdiv64(per_s, 64));
-  hipLaunchKernelGGL(conv_wgrad7_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)k.slab, (int)S, gx, CT, k.Cin, k.Cout, dW, I_total, o0, i0, db, scale);
+  hipLaunchKernelGGL(conv_wgrad7_reduce_kernel, dim3(rb), dim3(256), 0, st, (const float*)k.slab, (int)S, gx, CT, KS, k.Cin, k.Cout, dW, I_total, o0, i0, db, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }
@@ -1277,10 +1286,12 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
       if (rc <= 0) return rc;
     }
   }
-  if (ws && dtype == VMG_BF16 && ks == 7 && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW && (x_ps % 8 == 0) && (Cin % 8 == 0) && x_ps >= Cin &&
-      dy_ps >= Cout && Cout <= 64 && N > 0 && H > 0 && W > 0 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0 &&
-      (long long)npairs * N * cdiv(H, W7_R) * cdiv(W, 32) < (1LL << 30)) {
-    bool al = true, vdy = (dy_ps % 8 == 0) && (Cout % 8 == 0);
+  // 7x7 with <= 64 output channels and 3x3 with <= 16: one wave per tap row (conv_wgrad7_kernel)
+  const int rows_u = ks == 7 ? W7Geo<7>::R : W7Geo<3>::R;
+  if (ws && dtype == VMG_BF16 && ((ks == 7 && Cout <= 64) || (ks == 3 && Cout <= 16)) && npairs >= 1 && npairs <= WG_MAX_PAIRS && x && dy && dW &&
+      (x_ps % 8 == 0) && (Cin % 8 == 0) && x_ps >= Cin && dy_ps >= Cout && N > 0 && H > 0 && W > 0 && i0 >= 0 && i0 + Cin <= I_total && o0 >= 0 &&
+      (long long)npairs * N * cdiv(H, rows_u) * cdiv(W, 32) < (1LL << 30)) {
+    bool al = true, vdy = (dy_ps % 8 == 0);  // (channels past Cout inside the last vector are computed and dropped)
     for (int p = 0; al && p < npairs; ++p) {
       al = x[p] && dy[p] && ((uintptr_t)x[p] % 16 == 0) && ((uintptr_t)dy[p] % 2 == 0);
       vdy = vdy && ((uintptr_t)dy[p] % 16 == 0);
@@ -1290,14 +1301,15 @@ extern "C" int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const vo
       memset(&k, 0, sizeof(k));
       for (int p = 0; p < npairs; ++p) { k.x[p] = (const char*)x[p]; k.dy[p] = (const char*)dy[p]; }
       k.npairs = npairs; k.x_ps = x_ps; k.dy_ps = dy_ps; k.Cin = Cin; k.Cout = Cout; k.vec_dy = vdy ? 1 : 0; k.slab = (float*)ws;
-      k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32); k.HB = cdiv(H, W7_R);
+      k.N = N; k.H = H; k.W = W; k.SEG = cdiv(W, 32); k.HB = cdiv(H, rows_u);
       k.Upair = N * k.HB * k.SEG; k.U = k.Upair * npairs;
       k.has_bias = db != nullptr;
       hipStream_t st = (hipStream_t)stream;
       const int ct = cdiv(Cout, 16);
-      const int rc = ct == 1 ? launch_wgrad7<1>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
-                   : ct == 2 ? launch_wgrad7<2>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
-                             : launch_wgrad7<4>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st);
+      const int rc = ks == 3   ? launch_wgrad7<1, 3>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
+                     : ct == 1 ? launch_wgrad7<1>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
+                     : ct == 2 ? launch_wgrad7<2>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st)
+                               : launch_wgrad7<4>(k, dW, I_total, o0, i0, db, scale, ws_bytes, st);
       if (rc <= 0) return rc;
     }
   }
