@@ -230,6 +230,9 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
  *                    Backward of the activations fused in the conv epilogue (function.py:72,632; trajectory.py:33,188).
  * vmg_pixel_shuffle  to_depth = 0: (N,H,W,4c) -> (N,2H,2W,c) in torch nn.PixelShuffle(2) channel order
  *                    (models/vmg.py:380,629-630); to_depth = 1: the inverse (its backward).
+ * vmg_pixel_unshuffle_actgrad  the backward of "conv -> PixelShuffle(2) -> activation" in front of the conv's gradients, one pass:
+ *                    out[n,y,x,4c+2i+j] = dy[n,2y+i,2x+j,c] * alpha * act'(ref[n,2y+i,2x+j,c]); dy / ref (N,2H,2W,c), out (N,H,W,4c);
+ *                    ref = null with VMG_ACT_NONE.  c a multiple of the 16-byte vector (8 bf16 / 4 fp32).  models/vmg.py:629-630.
  * vmg_layernorm_fwd  y = (x - mean) * rstd * w + b over the last dim C of (M, C) rows, eps inside the sqrt; mean / rstd
  *                    (fp32, M each) are written when non-null.  nn.LayerNorm at function.py:1164,1195; layers.py:768-775;
  *                    swin_3d.py:717,741.
@@ -238,6 +241,8 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
 int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
                 void* stream);
 int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream);
+int vmg_pixel_unshuffle_actgrad(int dtype, const void* dy, const void* ref, void* out, int N, int H, int W, int c, int act, float slope,
+                                float alpha, void* stream);
 int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t M,
                       int C, float eps, void* stream);
 int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx,

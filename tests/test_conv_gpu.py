@@ -527,6 +527,27 @@ def test_conv3x3_small_cout_wgrad_kernel(shape):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])  # slabs are summed in a fixed order
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
+def test_pixel_unshuffle_actgrad_one_pass(dtype, act):
+    """The fused backward of conv -> PixelShuffle -> activation equals depth-to-space undone on both operands followed by the
+    activation derivative (bit for bit: same products, same rounding), and torch's pixel_unshuffle on the CPU."""
+    hip, K, O, R = _setup()
+    N, H, W, c = 2, 5, 7, 24
+    code = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU}[act]
+    dy = R.seeded((N, 2 * H, 2 * W, c), 301).to(dtype)
+    y = R.seeded((N, 2 * H, 2 * W, c), 302).to(dtype)
+    got = K.pixel_unshuffle_actgrad(dy.cuda(), y.cuda() if act != "none" else None, N, H, W, code, 0.1, 0.5)
+    d = {"none": torch.ones_like(y.float()), "relu": (y.float() > 0).float(), "lrelu": torch.where(y.float() > 0, 1.0, 0.1)}[act]
+    want_hi = (dy.float() * d * 0.5).to(dtype)
+    want = F.pixel_unshuffle(want_hi.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+    assert tuple(got.shape) == (N, H, W, 4 * c)
+    assert torch.equal(got.cpu(), want)
+    if act != "none":
+        two = K.act_backward(K.pixel_unshuffle(dy.cuda(), N, H, W), K.pixel_unshuffle(y.cuda(), N, H, W), code, 0.1, 0.5)
+        assert torch.equal(got, two)
+
+
 def test_repack_all_equals_individual_packs():
     """The one-launch repack plan (vmg_pack_entry / vmg_pack_run) rebuilds exactly the bytes the single pack calls produce: forward and
     data-gradient packs, both layouts, fp32 and bf16, 1x1 / 3x3 / 7x7, a channel slice, after an 'optimizer step' that rewrote the weights."""

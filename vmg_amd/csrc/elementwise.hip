@@ -66,6 +66,55 @@ __global__ void pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ o
   }
 }
 
+// Backward of a conv with a PixelShuffle store and an activation: dpre[n, y, x, 4c + 2i + j] = dy[n, 2y + i, 2x + j, c] * alpha * act'(ref[same])
+// in ONE pass (was: depth-to-space of dy, of the saved output, then act_bwd: 7 tensor passes over the HR map instead of 3).  A thread
+// owns V consecutive channels of one low-res pixel group: four 16-byte loads per operand, four 16-byte stores of 4V consecutive channels.
+template <typename T>
+__global__ void pixel_unshuffle_actgrad_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ out, int N, int H, int W, int c,
+                                               int act, float slope, float alpha) {
+  constexpr int V = Vec<T>::N;
+  const int cv = c / V;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    long long p = i / cv;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    float g[4][V];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long hi = (((long long)n * 2 * H + 2 * y + (r >> 1)) * (2 * W) + 2 * x + (r & 1)) * c + v * V;
+      const Vec<T> a = *reinterpret_cast<const Vec<T>*>(dy + hi);
+      Vec<T> u = a;
+      if (ref) u = *reinterpret_cast<const Vec<T>*>(ref + hi);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float d = 1.f;
+        if (ref) {
+          const float uf = to_f32(u.v[e]);
+          if (act == VMG_ACT_RELU) d = uf > 0.f ? 1.f : 0.f;
+          else if (act == VMG_ACT_LRELU) d = uf > 0.f ? 1.f : slope;
+          else if (act == VMG_ACT_GELU) d = gelu_erf_grad(uf);
+        }
+        g[r][e] = to_f32(a.v[e]) * d * alpha;
+      }
+    }
+    T* lo = out + (((long long)n * H + y) * W + x) * (4LL * c) + 4LL * v * V;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Vec<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int q = k * V + j;  // channel 4 * (v*V + q/4) + q%4 of the low-res pixel
+        o.v[j] = from_f32<T>(g[q & 3][q >> 2]);
+      }
+      reinterpret_cast<Vec<T>*>(lo)[k] = o;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------- LayerNorm
 // One row per group of G lanes (G = 16, 32 or 64 chosen from C); each lane keeps its vectors in registers.
 constexpr int LN_MAXV = 4;  // vectors per lane -> C <= 64 * 4 * 8 = 2048 (bf16), 1024 (fp32)
@@ -328,6 +377,24 @@ extern "C" int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, in
     if (to_depth) hipLaunchKernelGGL((pixel_shuffle_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W, c);
     else hipLaunchKernelGGL((pixel_shuffle_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W, c);
   }
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_pixel_unshuffle_actgrad(int dtype, const void* dy, const void* ref, void* out, int N, int H, int W, int c, int act, float slope,
+                                           float alpha, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "pixel_unshuffle_actgrad: bad dtype");
+  const int V = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(dy && out && N > 0 && H > 0 && W > 0 && c > 0 && c % V == 0, "pixel_unshuffle_actgrad: channels must be a multiple of %d", V);
+  VMG_CHECK((act == VMG_ACT_NONE) == (ref == nullptr), "pixel_unshuffle_actgrad: the activation needs its reference tensor (and only it)");
+  VMG_CHECK((uintptr_t)dy % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)ref % 16 == 0, "pixel_unshuffle_actgrad: 16-byte aligned tensors");
+  const long long total = (long long)N * H * W * (c / V);
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(pixel_unshuffle_actgrad_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)ref, (bf16*)out, N, H, W, c, act, slope, alpha);
+  else
+    hipLaunchKernelGGL(pixel_unshuffle_actgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)ref, (float*)out, N, H, W, c, act, slope, alpha);
   VMG_LAUNCH_CHECK();
   return 0;
 }

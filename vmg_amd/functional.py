@@ -427,11 +427,14 @@ class _Conv2d(_Fn):
         srcs_p = ctx.saved_tensors[3:]
         dy = dy.contiguous()
         d_res = dy.reshape(ctx.res_shape) if ctx.has_res else None
-        if pixel_shuffle:
-            # undo the depth-to-space on the gradient (and on y for the activation derivative)
-            dy = K.pixel_unshuffle(dy, N, H, W)
-            y = K.pixel_unshuffle(y, N, H, W) if y is not None else None
-        dpre = _act_grad(dy, y, pre, act, slope, alpha)
+        if pixel_shuffle and act != hip.ACT_GELU and dy.shape[-1] % (8 if dy.dtype == torch.bfloat16 else 4) == 0:
+            # depth-to-space undone on the gradient and the activation derivative taken from the HR output in one pass
+            dpre = K.pixel_unshuffle_actgrad(dy, y if act != hip.ACT_NONE else None, N, H, W, act, slope, alpha)
+        else:
+            if pixel_shuffle:
+                dy = K.pixel_unshuffle(dy, N, H, W)
+                y = K.pixel_unshuffle(y, N, H, W) if y is not None else None
+            dpre = _act_grad(dy, y, pre, act, slope, alpha)
         O = weight.shape[0]
         I = weight.shape[1]
         d_w = d_b = None

@@ -333,6 +333,19 @@ def pixel_shuffle(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def pixel_unshuffle_actgrad(dy: torch.Tensor, ref: Optional[torch.Tensor], N: int, H: int, W: int, act: int, slope: float, alpha: float) -> torch.Tensor:
+    """(N,2H,2W,c) gradient (and activation reference) -> (N,H,W,4c) pre-activation gradient of a PixelShuffle conv, one pass."""
+    hip.require_cuda(dy, ref)
+    c = dy.shape[-1]
+    if dy.numel() != 4 * N * H * W * c or not dy.is_contiguous() or (ref is not None and (ref.shape != dy.shape or ref.dtype != dy.dtype or not ref.is_contiguous())):
+        raise HipError("pixel_unshuffle_actgrad: bad input")
+    out = torch.empty((N, H, W, 4 * c), dtype=dy.dtype, device=dy.device)
+    hip.check(hip.lib().vmg_pixel_unshuffle_actgrad(hip.dtype_code(dy.dtype), dy.data_ptr(), ref.data_ptr() if ref is not None else None, out.data_ptr(),
+                                                    N, H, W, c, act if ref is not None else hip.ACT_NONE, slope, alpha, hip.stream_ptr()),
+              "vmg_pixel_unshuffle_actgrad")
+    return out
+
+
 def pixel_unshuffle(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
     """(N,2H,2W,c) -> (N,H,W,4c): inverse of pixel_shuffle."""
     hip.require_cuda(x)
