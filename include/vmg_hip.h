@@ -301,15 +301,16 @@ int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int
  *   q (n,h,w,c); keys[j], vals[j] (n,h,w,c) for key-frame j = 0 (oldest) .. t-1; loc (n,2t,h,w) fp32 tracked pixel
  *   coordinates (x plane then y plane per key-frame); rpe (heads, wh*ww, wh*ww) fp32; decay (heads) fp32.
  *   out (n,h,w,c); lse (n,h,w,heads) fp32 log-sum-exp, kept for the backward pass.
- * Backward: dq (n,h,w,c); dk_acc[j], dv_acc[j] fp32 (n,h,w,c) caller-zeroed accumulators (gradients are scattered to the
- * gathered source pixels with float atomics); drpe (heads, wq, wq) fp32 accumulated.  heads must be 4.
+ * Backward: dq (n,h,w,c); dk_acc[j], dv_acc[j] (n,h,w,c) caller-zeroed accumulators OF THE TENSORS' DTYPE (gradients are scattered to
+ * the gathered source pixels with atomics: float atomics for fp32, packed bf16 atomics for bf16); drpe (heads, wq, wq) fp32
+ * accumulated.  heads must be 4.
  * ---------------------------------------------------------------------------------------------- */
 int vmg_ltam_fwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc, const float* rpe,
                  const float* decay, void* out, float* lse, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
                  void* stream);
 int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc, const float* rpe,
-                 const float* decay, const void* out, const float* lse, const void* dout, void* dq, float* const* dk_acc,
-                 float* const* dv_acc, float* drpe, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
+                 const float* decay, const void* out, const float* lse, const void* dout, void* dq, void* const* dk_acc,
+                 void* const* dv_acc, float* drpe, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------

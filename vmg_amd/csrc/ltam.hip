@@ -33,12 +33,13 @@ struct LtamK {
   // backward
   const char* dout;
   char* dq;            // (n,h,w,c) T
-  float* dk_acc[LT_MAX_T];  // fp32 (n,h,w,c) accumulators, zero-initialised
-  float* dv_acc[LT_MAX_T];
+  void* dk_acc[LT_MAX_T];  // (n,h,w,c) accumulators in the tensors' dtype, zero-initialised
+  void* dv_acc[LT_MAX_T];
   float* drpe;         // (heads, wq, wq) fp32, accumulated
   int n, h, w, c, t, wh, ww;
   float scale;
   int tiles_x, tiles_y;
+  int dbg;  // diagnostics build only (env VMG_LTAM_DBG): 1 no scatter of dK / dV, 2 no key side, 4 no query side, 8 no gathers after the first key-frame
 };
 
 __device__ __forceinline__ int nearest_index(float lx, float ly, int w, int h) {
@@ -59,24 +60,64 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 head-thr
   return v;
 }
 
-// cooperative copy of one pixel row (c elements) per tile pixel into LDS; src_idx < 0 -> zeros
-template <typename T>
-__device__ __forceinline__ void stage_rows(T* dst, int row_stride, const T* src_base, const int* src_idx, int c, int tid) {
-  constexpr int VN = 16 / sizeof(T);
-  const int nvec = c / VN;
-  for (int i = tid; i < LT_PIX * nvec; i += 256) {
-    const int p = i / nvec, v = i - p * nvec;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    const int s = src_idx[p];
-    if (s >= 0) val = *reinterpret_cast<const uint4*>(src_base + (long long)s * c + v * VN);
-    *reinterpret_cast<uint4*>(dst + p * row_stride + v * VN) = val;
+// cooperative copy of one pixel row (c = 4 D elements) per tile pixel into LDS; src_idx < 0 -> zeros.  Every load is UNCONDITIONAL (a row
+// without a source reads the zero vector) and all of a thread's loads are issued before the first LDS store: loads behind a per-lane
+// branch are each followed by s_waitcnt vmcnt(0), which serialised 4-5 gather latencies per tile and key-frame.
+typedef __attribute__((ext_vector_type(4))) unsigned int lt_u32x4;  // (a native vector: the HIP uint4 struct behind a pointer select goes through scratch)
+__device__ __attribute__((aligned(16))) const unsigned int g_ltam_zero[4] = {0, 0, 0, 0};
+
+template <typename T, int D>
+struct RowCopy {
+  static constexpr int VN = 16 / sizeof(T), NVEC = LT_HEADS * D / VN, TOTAL = LT_PIX * NVEC, NIT = (TOTAL + 255) / 256;
+  lt_u32x4 r[NIT];
+  __device__ __forceinline__ void fetch(const T* src_base, const int* src_idx, int tid) {
+    constexpr int c = LT_HEADS * D;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + k * 256;
+      const int p = min(i / NVEC, LT_PIX - 1), v = i - (i / NVEC) * NVEC;
+      const int s_ = src_idx[p];
+      const bool ok = i < TOTAL && s_ >= 0;
+      const T* src = ok ? src_base + (long long)s_ * c + v * VN : reinterpret_cast<const T*>(g_ltam_zero);
+      r[k] = *reinterpret_cast<const lt_u32x4*>(src);
+    }
+  }
+  __device__ __forceinline__ void store(T* dst, int row_stride, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + k * 256;
+      const int p = i / NVEC, v = i - p * NVEC;
+      if (i < TOTAL) *reinterpret_cast<lt_u32x4*>(dst + p * row_stride + v * VN) = r[k];
+    }
+  }
+};
+
+// the D-channel slice of one head as floats, read with 8-byte (bf16) / 16-byte (fp32) vectors: D is a multiple of 4, rows and head slices
+// start on those boundaries (c = 4 D; the LDS row stride is c + one 16-byte vector)
+template <typename T, int D>
+__device__ __forceinline__ void load_slice(const T* p, float (&o)[D]) {
+  static_assert(D % 4 == 0, "head dim must be a multiple of 4");
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < D / 4; ++i) {
+      const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[4 * i + e] = (float)t[e];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D / 4; ++i) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[4 * i + e] = t[e];
+    }
   }
 }
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int c = a.c, RS = c + 16 / sizeof(T);  // padded row stride (elements)
+  constexpr int c = LT_HEADS * D, RS = c + 16 / sizeof(T);  // channels (== a.c: the dispatch picks D from it), padded row stride (elements)
   T* qt = reinterpret_cast<T*>(smem);
   T* kt = qt + LT_PIX * RS;
   T* vt = kt + LT_PIX * RS;
@@ -98,13 +139,16 @@ __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
     selfidx[tid] = (yy < a.h && xx < a.w) ? yy * a.w + xx : -1;
   }
   __syncthreads();
-  stage_rows<T>(qt, RS, reinterpret_cast<const T*>(a.q) + img * c, selfidx, c, tid);
+  RowCopy<T, D> rk, rv;
+  rk.fetch(reinterpret_cast<const T*>(a.q) + img * c, selfidx, tid);
+  rk.store(qt, RS, tid);
   __syncthreads();
   // normalised, scaled query slice in registers
   float qs[D];
   float ss = 0.f;
+  load_slice<T, D>(qt + p * RS + hd * D, qs);
 #pragma unroll
-  for (int d = 0; d < D; ++d) { qs[d] = to_f32(qt[p * RS + hd * D + d]); ss += qs[d] * qs[d]; }
+  for (int d = 0; d < D; ++d) ss += qs[d] * qs[d];
   {
     const float inv = a.scale / fmaxf(sqrtf(quad_sum(ss)), 1e-12f);
 #pragma unroll
@@ -129,13 +173,16 @@ __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
       sidx[tid] = s;
     }
     __syncthreads();
-    stage_rows<T>(kt, RS, reinterpret_cast<const T*>(a.k[j]) + img * c, sidx, c, tid);
-    stage_rows<T>(vt, RS, reinterpret_cast<const T*>(a.v[j]) + img * c, sidx, c, tid);
+    rk.fetch(reinterpret_cast<const T*>(a.k[j]) + img * c, sidx, tid);
+    rv.fetch(reinterpret_cast<const T*>(a.v[j]) + img * c, sidx, tid);
+    rk.store(kt, RS, tid);
+    rv.store(vt, RS, tid);
     __syncthreads();
     {
-      float s2 = 0.f;
+      float s2 = 0.f, kv[D];
+      load_slice<T, D>(kt + p * RS + hd * D, kv);
 #pragma unroll
-      for (int d = 0; d < D; ++d) { const float kv = to_f32(kt[p * RS + hd * D + d]); s2 += kv * kv; }
+      for (int d = 0; d < D; ++d) s2 += kv[d] * kv[d];
       s2 = quad_sum(s2);
       if (hd == 0) knorm[p] = fmaxf(sqrtf(s2), 1e-12f);
     }
@@ -144,15 +191,17 @@ __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
     for (int e = 1; e < a.t - j; ++e) pw *= dec;
     for (int ki = 0; ki < wq; ++ki) {
       const int pk = (wy0 + ki / a.ww) * LT_TILE + wx0 + ki % a.ww;
-      float dot = 0.f;
+      float dot = 0.f, kk[D], vv[D];
+      load_slice<T, D>(kt + pk * RS + hd * D, kk);
+      load_slice<T, D>(vt + pk * RS + hd * D, vv);
 #pragma unroll
-      for (int d = 0; d < D; ++d) dot += qs[d] * to_f32(kt[pk * RS + hd * D + d]);
+      for (int d = 0; d < D; ++d) dot += qs[d] * kk[d];
       const float logit = dot / knorm[pk] + pw * a.rpe[(hd * wq + qi) * wq + ki];
       const float mn = fmaxf(m, logit);
       const float corr = __expf(m - mn), pe = __expf(logit - mn);
       l = l * corr + pe;
 #pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = acc[d] * corr + pe * to_f32(vt[pk * RS + hd * D + d]);
+      for (int d = 0; d < D; ++d) acc[d] = acc[d] * corr + pe * vv[d];
       m = mn;
     }
   }
@@ -169,19 +218,57 @@ __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
 //   as a QUERY: accumulates dqn (gradient of its normalised query slice) over all keys,
 //   as a KEY/VALUE position: accumulates dkn, dv of ITS gathered row over the wq queries of its window,
 // then the normalisation Jacobians are applied and dK/dV rows are scattered (float atomics) to the gather sources.
+// Scatter-add of the tile's 64 gradient rows (fp32 in LDS, [64][C]) to their gather sources.  Lanes run along CHANNELS: every atomic
+// wave-instruction adds 256 contiguous bytes -- the full-rate shape of global atomics here (a lane-per-head-slice scatter strides the lanes
+// by D elements and was ~10x slower).  fp32 tensors: float atomics.  bf16 tensors: PACKED bf16 atomics (global_atomic_pk_add_bf16, two
+// channels per lane) straight into a bf16 accumulator: half the atomic instructions, and neither a zero-fill nor a cast pass over an fp32
+// copy of every key / value frame (a third of the backward's time at 6 key-frames); several rows landing on one source pixel are then
+// summed in bf16, as autograd sums the bf16 gradients of the calls that share a key-frame anyway.
+typedef __attribute__((ext_vector_type(2))) short lt_s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 lt_bf16x2;
+template <typename T, int C>
+__device__ __forceinline__ void scatter_rows(void* acc, long long img, const float* rowbuf, const int* sidx, const int* selfidx, int tid, bool skip) {
+  if constexpr (sizeof(T) == 2) {
+    constexpr int C2 = C / 2;
+    bf16* dst = reinterpret_cast<bf16*>(acc);
+    for (int i = tid; i < LT_PIX * C2; i += 256) {
+      const int pp = i / C2, ch = 2 * (i - pp * C2);
+      const int sp = sidx[pp];
+      if (sp >= 0 && selfidx[pp] >= 0 && !skip) {
+        const lt_bf16x2 v = {(bf16)rowbuf[pp * C + ch], (bf16)rowbuf[pp * C + ch + 1]};
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) lt_s16x2*)(dst + (img + sp) * C + ch),
+                                                   __builtin_bit_cast(lt_s16x2, v));
+      }
+    }
+  } else {
+    float* dst = reinterpret_cast<float*>(acc);
+    for (int i = tid; i < LT_PIX * C; i += 256) {
+      const int pp = i / C, ch = i - pp * C;
+      const int sp = sidx[pp];
+      if (sp >= 0 && selfidx[pp] >= 0 && !skip) atomicAdd(dst + (img + sp) * C + ch, rowbuf[i]);
+    }
+  }
+}
+
+#ifdef VMG_DIAG
+#define LT_ABL(bit) (a.dbg & (bit))
+#else
+#define LT_ABL(bit) false
+#endif
 template <typename T, int D>
 __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int c = a.c, RS = c + 16 / sizeof(T);
+  constexpr int c = LT_HEADS * D, RS = c + 16 / sizeof(T);
   T* kt = reinterpret_cast<T*>(smem);
   T* vt = kt + LT_PIX * RS;
   T* dot_ = vt + LT_PIX * RS;  // dout tile (read by the key-side pass of window mates)
-  float* knorm = reinterpret_cast<float*>(dot_ + LT_PIX * RS);
+  T* qt = dot_ + LT_PIX * RS;  // raw q tile (same)
+  float* knorm = reinterpret_cast<float*>(qt + LT_PIX * RS);
   float* qnorm = knorm + LT_PIX;
   float* lse = qnorm + LT_PIX;             // [64][4]
   float* delta = lse + LT_PIX * LT_HEADS;  // [64][4]
-  float* drpe_s = delta + LT_PIX * LT_HEADS;  // [heads][wq][wq] <= 4*16*16... wq <= 16
-  int* sidx = reinterpret_cast<int*>(drpe_s + LT_HEADS * 16 * 16);
+  float* drpe_s = delta + LT_PIX * LT_HEADS;  // [heads][wq][wq]
+  int* sidx = reinterpret_cast<int*>(drpe_s + LT_HEADS * a.wh * a.ww * a.wh * a.ww);
   int* selfidx = sidx + LT_PIX;
 
   const int tid = threadIdx.x, p = tid >> 2, hd = tid & 3;
@@ -200,18 +287,23 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
   }
   for (int i = tid; i < LT_HEADS * wq * wq; i += 256) drpe_s[i] = 0.f;
   __syncthreads();
-  stage_rows<T>(dot_, RS, reinterpret_cast<const T*>(a.dout) + img * c, selfidx, c, tid);
+  RowCopy<T, D> rk, rv;
+  rk.fetch(reinterpret_cast<const T*>(a.dout) + img * c, selfidx, tid);
+  rv.fetch(reinterpret_cast<const T*>(a.q) + img * c, selfidx, tid);
+  rk.store(dot_, RS, tid);
+  rv.store(qt, RS, tid);
   __syncthreads();
   float qn[D], go[D];  // normalised query slice (unscaled), dout slice
   {
-    float ss = 0.f, dl = 0.f;
-    const long long own = (img + (long long)y * a.w + x) * c + hd * D;
+    float ss = 0.f, dl = 0.f, ov[D];
+    const long long own = (img + (long long)(inside ? y * a.w + x : 0)) * c + hd * D;  // (tile pixels outside the image read pixel 0 and drop it)
+    load_slice<T, D>(qt + p * RS + hd * D, qn);
+    load_slice<T, D>(dot_ + p * RS + hd * D, go);
+    load_slice<T, D>(reinterpret_cast<const T*>(a.out) + own, ov);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      qn[d] = inside ? to_f32(reinterpret_cast<const T*>(a.q)[own + d]) : 0.f;
-      go[d] = to_f32(dot_[p * RS + hd * D + d]);
       ss += qn[d] * qn[d];
-      dl += inside ? go[d] * to_f32(reinterpret_cast<const T*>(a.out)[own + d]) : 0.f;
+      dl += inside ? go[d] * ov[d] : 0.f;
     }
     const float nr = fmaxf(sqrtf(quad_sum(ss)), 1e-12f);
     if (hd == 0) qnorm[p] = nr;
@@ -238,14 +330,20 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
       sidx[tid] = s;
     }
     __syncthreads();
-    stage_rows<T>(kt, RS, reinterpret_cast<const T*>(a.k[j]) + img * c, sidx, c, tid);
-    stage_rows<T>(vt, RS, reinterpret_cast<const T*>(a.v[j]) + img * c, sidx, c, tid);
+    if (!(LT_ABL(8) && j > 0)) {
+      rk.fetch(reinterpret_cast<const T*>(a.k[j]) + img * c, sidx, tid);
+      rv.fetch(reinterpret_cast<const T*>(a.v[j]) + img * c, sidx, tid);
+    }
+    rk.store(kt, RS, tid);
+    rv.store(vt, RS, tid);
     __syncthreads();
-    float kn[D];  // this thread's key slice (raw, then normalised)
+    float kn[D], vown[D];  // this thread's key slice (raw, then normalised) and value slice
+    load_slice<T, D>(vt + p * RS + hd * D, vown);
     {
       float s2 = 0.f;
+      load_slice<T, D>(kt + p * RS + hd * D, kn);
 #pragma unroll
-      for (int d = 0; d < D; ++d) { kn[d] = to_f32(kt[p * RS + hd * D + d]); s2 += kn[d] * kn[d]; }
+      for (int d = 0; d < D; ++d) s2 += kn[d] * kn[d];
       s2 = quad_sum(s2);
       const float nr = fmaxf(sqrtf(s2), 1e-12f);
       if (hd == 0) knorm[p] = nr;
@@ -258,16 +356,18 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
     for (int e = 1; e < a.t - j; ++e) pw *= dec;
 
     // ---- query side: dqn += sum_k ds * scale * kn_k ; drpe
-    {
+    if (!LT_ABL(4)) {
       const float my_lse = lse[p * LT_HEADS + hd], my_delta = delta[p * LT_HEADS + hd];
       for (int ki = 0; ki < wq; ++ki) {
         const int pk = (wy0 + ki / a.ww) * LT_TILE + wx0 + ki % a.ww;
         const float inv_kn = 1.f / knorm[pk];
-        float dot = 0.f, dp = 0.f;
+        float dot = 0.f, dp = 0.f, kk[D], vv[D];
+        load_slice<T, D>(kt + pk * RS + hd * D, kk);
+        load_slice<T, D>(vt + pk * RS + hd * D, vv);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          dot += qn[d] * to_f32(kt[pk * RS + hd * D + d]);
-          dp += go[d] * to_f32(vt[pk * RS + hd * D + d]);
+          dot += qn[d] * kk[d];
+          dp += go[d] * vv[d];
         }
         const float logit = a.scale * dot * inv_kn + pw * a.rpe[(hd * wq + myi) * wq + ki];
         const float pr = __expf(logit - my_lse);
@@ -275,7 +375,7 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
         if (inside) atomicAdd(&drpe_s[(hd * wq + myi) * wq + ki], ds * pw);
         const float f = ds * a.scale * inv_kn;
 #pragma unroll
-        for (int d = 0; d < D; ++d) dqn[d] += f * to_f32(kt[pk * RS + hd * D + d]);
+        for (int d = 0; d < D; ++d) dqn[d] += f * kk[d];
       }
     }
     // ---- key side: this thread's gathered row (p, key-frame j) against the wq queries of its window
@@ -284,18 +384,18 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
     for (int d = 0; d < D; ++d) dkn[d] = dv[d] = 0.f;
     for (int qq = 0; qq < wq; ++qq) {
       const int pq = (wy0 + qq / a.ww) * LT_TILE + wx0 + qq % a.ww;
-      if (selfidx[pq] < 0) continue;
+      if (selfidx[pq] < 0 || LT_ABL(2)) continue;
       // query pq's normalised slice: recompute from the raw q tile would need its norm -> qnorm[] holds it
       const float inv_qn = 1.f / qnorm[pq];
       float dot = 0.f, dp = 0.f;
-      const T* qraw = reinterpret_cast<const T*>(a.q) + (img + selfidx[pq]) * c + hd * D;
-      const T* graw = dot_ + pq * RS + hd * D;
-      float qv[D];
+      float qv[D], gg[D];
+      load_slice<T, D>(qt + pq * RS + hd * D, qv);
+      load_slice<T, D>(dot_ + pq * RS + hd * D, gg);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        qv[d] = to_f32(qraw[d]) * inv_qn;
+        qv[d] *= inv_qn;
         dot += qv[d] * kn[d];
-        dp += to_f32(graw[d]) * to_f32(vt[p * RS + hd * D + d]);
+        dp += gg[d] * vown[d];
       }
       const float logit = a.scale * dot + pw * a.rpe[(hd * wq + qq) * wq + myi];
       const float pr = __expf(logit - lse[pq * LT_HEADS + hd]);
@@ -303,14 +403,12 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         dkn[d] += ds * a.scale * qv[d];
-        dv[d] += pr * to_f32(graw[d]);
+        dv[d] += pr * gg[d];
       }
     }
-    // normalisation Jacobian of the key row; then the rows are scattered to their gather sources.  The scatter goes
-    // through LDS so that lanes run along CHANNELS: each atomic wave-instruction adds 64 consecutive floats (256
-    // contiguous bytes = the full-rate shape of global float atomics here; a lane-per-head-slice scatter strides the
-    // lanes by D floats and was ~10x slower).  The K/V tiles of this key-frame are dead by now and are reused as the
-    // fp32 row buffer [64][c] (kt and vt are contiguous: 2 tiles hold 64*c floats for bf16 and fp32 alike).
+    // normalisation Jacobian of the key row; then the rows are scattered to their gather sources through LDS (scatter_rows).  The K/V
+    // tiles of this key-frame are dead by now and are reused as the fp32 row buffer [64][c] (kt and vt are contiguous: 2 tiles hold
+    // 64*c floats for bf16 and fp32 alike).
     {
       float nd = 0.f;
 #pragma unroll
@@ -322,20 +420,12 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
 #pragma unroll
       for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = (dkn[d] - kn[d] * nd) * inv;
       __syncthreads();
-      for (int i = tid; i < LT_PIX * c; i += 256) {
-        const int pp = i / c, ch = i - pp * c;
-        const int sp = sidx[pp];
-        if (sp >= 0 && selfidx[pp] >= 0) atomicAdd(a.dk_acc[j] + (img + sp) * c + ch, rowbuf[i]);
-      }
+      scatter_rows<T, c>(a.dk_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
       __syncthreads();
 #pragma unroll
       for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = dv[d];
       __syncthreads();
-      for (int i = tid; i < LT_PIX * c; i += 256) {
-        const int pp = i / c, ch = i - pp * c;
-        const int sp = sidx[pp];
-        if (sp >= 0 && selfidx[pp] >= 0) atomicAdd(a.dv_acc[j] + (img + sp) * c + ch, rowbuf[i]);
-      }
+      scatter_rows<T, c>(a.dv_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
     }
   }
   // query normalisation Jacobian
@@ -367,7 +457,9 @@ int launch_ltam(const LtamK& k, bool backward, hipStream_t st) {
     if (!set[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set[dev] = true; }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, k);
   } else {
-    const int lds = 3 * LT_PIX * RS * (int)sizeof(T) + (2 * LT_PIX + 2 * LT_PIX * LT_HEADS + LT_HEADS * 256) * 4 + 2 * LT_PIX * 4;
+    const int wq = k.wh * k.ww;
+    // (bf16, 144 channels, 2 x 2 windows: 81 152 B -- two workgroups per CU)
+    const int lds = 4 * LT_PIX * RS * (int)sizeof(T) + (2 * LT_PIX + 2 * LT_PIX * LT_HEADS + LT_HEADS * wq * wq) * 4 + 2 * LT_PIX * 4;
     VMG_CHECK(lds <= 160 * 1024, "ltam_bwd: LDS request %d B exceeds 160 KiB", lds);
     auto fn = ltam_bwd_kernel<T, D>;
     static bool set[VMG_MAX_DEVICES] = {};  // the attribute is per device
@@ -427,11 +519,14 @@ extern "C" int vmg_ltam_fwd(int dtype, const void* q, const void* const* keys, c
 
 extern "C" int vmg_ltam_bwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc,
                             const float* rpe, const float* decay, const void* out, const float* lse, const void* dout, void* dq,
-                            float* const* dk_acc, float* const* dv_acc, float* drpe, int n, int h, int w, int c, int heads, int wh,
+                            void* const* dk_acc, void* const* dv_acc, float* drpe, int n, int h, int w, int c, int heads, int wh,
                             int ww, int t, float scale, void* stream) {
   LtamK k;
   if (int rc = fill_common(k, dtype, q, keys, vals, loc, rpe, decay, n, h, w, c, heads, wh, ww, t, scale)) return rc;
   VMG_CHECK(out && lse && dout && dq && dk_acc && dv_acc && drpe, "ltam_bwd: null pointer");
+#ifdef VMG_DIAG
+  { const char* e = getenv("VMG_LTAM_DBG"); k.dbg = e ? atoi(e) : 0; }
+#endif
   k.out = (char*)out; k.lse = (float*)lse; k.dout = (const char*)dout; k.dq = (char*)dq; k.drpe = drpe;
   for (int j = 0; j < t; ++j) {
     VMG_CHECK(dk_acc[j] && dv_acc[j], "ltam_bwd: null accumulator %d", j);

@@ -742,17 +742,13 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
     t = len(keys)
     dout = dout.contiguous()
     dq = torch.empty_like(q)
-    acc = torch.zeros((2 * t, n, h, w, c), dtype=torch.float32, device=q.device)
+    acc = torch.zeros((2 * t, n, h, w, c), dtype=q.dtype, device=q.device)  # (bf16: packed bf16 atomics -- no fp32 copy, no cast pass)
     drpe = torch.zeros_like(rpe)
     dk = [acc[j] for j in range(t)]
     dv = [acc[t + j] for j in range(t)]
     hip.check(hip.lib().vmg_ltam_bwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
                                      decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
                                      drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")
-    if q.dtype != torch.float32:  # ONE cast of the whole accumulator block instead of one per key / value frame
-        acc = acc.to(q.dtype)
-        dk = [acc[j] for j in range(t)]
-        dv = [acc[t + j] for j in range(t)]
     return dq, dk, dv, drpe
 
 
