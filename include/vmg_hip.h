@@ -287,11 +287,12 @@ int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const
  * Flow-guided sampling of the trajectory recurrence (models/trajectory.py:71-116 flow_warp, :329-333, :414-417).
  * flow: (N,H,W,2) fp32 pixel offsets (x then y); coordinates follow flow_warp + F.grid_sample(align_corners=True).
  *   vmg_warp_bilinear_fwd   out[n,y,x,:] = bilinear sample of x at (x + flow_x, y + flow_y), border padding.
- *   vmg_warp_bilinear_bwd   dx_acc (fp32, caller-zeroed, (N,H,W,C)) += scatter of dy; dflow (fp32, caller-zeroed) += d/dflow.
+ *   vmg_warp_bilinear_bwd   dx_acc ((N,H,W,C), the tensors' dtype, caller-zeroed) += scatter of dy (float atomics; bf16: packed bf16
+ *                           atomics, C even); dflow (fp32, (N,H,W,2)) = d/dflow, every element written.
  *   vmg_warp_nearest_planes advects the tracked-location maps (N,K2,H,W) fp32 with nearest sampling, border padding.
  * ---------------------------------------------------------------------------------------------- */
 int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out, int N, int H, int W, int C, void* stream);
-int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, float* dx_acc, float* dflow, int N, int H,
+int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, void* dx_acc, float* dflow, int N, int H,
                           int W, int C, void* stream);
 int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int N, int K2, int H, int W, void* stream);
 

@@ -74,13 +74,18 @@ __global__ __launch_bounds__(256) void warp_bilinear_fwd_kernel(const T* __restr
   }
 }
 
-// backward: dx_acc (fp32, zero-initialised) += scatter of dy; dflow = channel reductions.
-// One WAVE per output pixel, lanes along channels: every atomic wave-instruction adds 64 consecutive floats (256
-// contiguous bytes, the full-rate shape of global float atomics on this chip; a lane-per-vector mapping strides the
-// lanes by 32 B and ran 10x slower), and the flow gradient is a wave reduction written without atomics.
+// backward: dx_acc (zero-initialised, the tensors' dtype) += scatter of dy; dflow = channel reductions.
+// One WAVE per output pixel, lanes along channels: every atomic wave-instruction adds 256 contiguous bytes, the full-rate shape of
+// global atomics on this chip (a lane-per-vector mapping strides the lanes by 32 B and ran 10x slower), and the flow gradient is a
+// wave reduction written without atomics.  fp32: float atomics, one channel per lane.  bf16: PACKED bf16 atomics
+// (global_atomic_pk_add_bf16), two channels per lane, straight into a bf16 accumulator -- a third fewer atomic instructions at 144
+// channels and neither a zero-fill nor a cast pass over an fp32 copy of the frame; the up to four (typically) contributions a source
+// pixel receives are summed in bf16.
+typedef __attribute__((ext_vector_type(2))) short wp_s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 wp_bf16x2;
 template <typename T>
 __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow,
-                                                                const T* __restrict__ dy, float* __restrict__ dx_acc,
+                                                                const T* __restrict__ dy, T* __restrict__ dx_acc,
                                                                 float* __restrict__ dflow, int N, int H, int W, int C) {
   const int lane = threadIdx.x & 63;
   const long long npix = (long long)N * H * W;
@@ -103,12 +108,32 @@ __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restr
     const long long onw = ib + ((long long)y0 * W + x0) * C, one = ib + ((long long)y0 * W + x1) * C;
     const long long osw = ib + ((long long)y1 * W + x0) * C, ose = ib + ((long long)y1 * W + x1) * C;
     float gix = 0.f, giy = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float g = to_f32(dy[pix * C + c]);
-      if (vnw) { atomicAdd(dx_acc + onw + c, g * wnw); const float xv = to_f32(x[onw + c]) * g; gix -= xv * (1.f - ty); giy -= xv * (1.f - tx); }
-      if (vne) { atomicAdd(dx_acc + one + c, g * wne); const float xv = to_f32(x[one + c]) * g; gix += xv * (1.f - ty); giy -= xv * tx; }
-      if (vsw) { atomicAdd(dx_acc + osw + c, g * wsw); const float xv = to_f32(x[osw + c]) * g; gix -= xv * ty; giy += xv * (1.f - tx); }
-      if (vse) { atomicAdd(dx_acc + ose + c, g * wse); const float xv = to_f32(x[ose + c]) * g; gix += xv * ty; giy += xv * tx; }
+    if constexpr (sizeof(T) == 2) {
+      typedef __attribute__((address_space(1))) wp_s16x2* gptr;
+      for (int c = 2 * lane; c < C; c += 128) {  // (C is even: the host checks)
+        const wp_bf16x2 gp = *reinterpret_cast<const wp_bf16x2*>(dy + pix * C + c);
+        const float g0 = (float)gp[0], g1 = (float)gp[1];
+        auto corner = [&](long long o, float wgt, float sx, float sy) __attribute__((always_inline)) {
+          const wp_bf16x2 a = {(__bf16)(g0 * wgt), (__bf16)(g1 * wgt)};
+          __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr)(dx_acc + o + c), __builtin_bit_cast(wp_s16x2, a));
+          const wp_bf16x2 xp = *reinterpret_cast<const wp_bf16x2*>(x + o + c);
+          const float xv = (float)xp[0] * g0 + (float)xp[1] * g1;
+          gix += xv * sx;
+          giy += xv * sy;
+        };
+        if (vnw) corner(onw, wnw, -(1.f - ty), -(1.f - tx));
+        if (vne) corner(one, wne, (1.f - ty), -tx);
+        if (vsw) corner(osw, wsw, -ty, (1.f - tx));
+        if (vse) corner(ose, wse, ty, tx);
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float g = to_f32(dy[pix * C + c]);
+        if (vnw) { atomicAdd(dx_acc + onw + c, g * wnw); const float xv = to_f32(x[onw + c]) * g; gix -= xv * (1.f - ty); giy -= xv * (1.f - tx); }
+        if (vne) { atomicAdd(dx_acc + one + c, g * wne); const float xv = to_f32(x[one + c]) * g; gix += xv * (1.f - ty); giy -= xv * tx; }
+        if (vsw) { atomicAdd(dx_acc + osw + c, g * wsw); const float xv = to_f32(x[osw + c]) * g; gix -= xv * ty; giy += xv * (1.f - tx); }
+        if (vse) { atomicAdd(dx_acc + ose + c, g * wse); const float xv = to_f32(x[ose + c]) * g; gix += xv * ty; giy += xv * tx; }
+      }
     }
     gix = wave_sum(gix);
     giy = wave_sum(giy);
@@ -161,7 +186,7 @@ extern "C" int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow
   return 0;
 }
 
-extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, float* dx_acc, float* dflow, int N,
+extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, void* dx_acc, float* dflow, int N,
                                      int H, int W, int C, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "warp_bwd: bad dtype");
   VMG_CHECK(x && flow && dy && dx_acc && dflow && N > 0 && H > 0 && W > 0 && C > 0, "warp_bwd: bad arguments");
@@ -169,8 +194,12 @@ extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow
   (void)vn;
   const long long total = (long long)N * H * W * 64;  // one wave per pixel
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VMG_BF16) hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, dx_acc, dflow, N, H, W, C);
-  else hipLaunchKernelGGL(warp_bilinear_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (const float*)dy, dx_acc, dflow, N, H, W, C);
+  if (dtype == VMG_BF16) {
+    VMG_CHECK(C % 2 == 0 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx_acc) % 4 == 0, "warp_bwd: bf16 needs an even channel count and 4-byte aligned tensors");
+    hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, (bf16*)dx_acc, dflow, N, H, W, C);
+  } else {
+    hipLaunchKernelGGL(warp_bilinear_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (const float*)dy, (float*)dx_acc, dflow, N, H, W, C);
+  }
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -698,8 +698,8 @@ def warp_bilinear_forward(x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
 def warp_bilinear_backward(x: torch.Tensor, flow: torch.Tensor, dy: torch.Tensor):
     n, h, w, c = x.shape
     dy = dy.contiguous()
-    dx_acc = torch.zeros((n, h, w, c), dtype=torch.float32, device=x.device)
-    dflow = torch.zeros((n, h, w, 2), dtype=torch.float32, device=x.device)
+    dx_acc = torch.zeros((n, h, w, c), dtype=x.dtype, device=x.device)  # (bf16: packed bf16 atomics, no fp32 copy)
+    dflow = torch.empty((n, h, w, 2), dtype=torch.float32, device=x.device)  # every element is written
     hip.check(hip.lib().vmg_warp_bilinear_bwd(hip.dtype_code(x.dtype), x.data_ptr(), flow.data_ptr(), dy.data_ptr(), dx_acc.data_ptr(),
                                               dflow.data_ptr(), n, h, w, c, hip.stream_ptr()), "vmg_warp_bilinear_bwd")
     return dx_acc, dflow
