@@ -335,9 +335,13 @@ double vmg_prof_null_interval_us(int reps, void* stream);
  * the (Cp, Cp) weight (ks = 1, one source of Cp channels, cout_tiles = ceil(Cp / 16)); the caller packs AFTER applying the retention decay
  * W <- W * Gamma (function.py:766-768).  relu_mask (may be null): the data-gradient form -- x is multiplied by (relu_mask > 0) * in_scale on the way
  * in (relu_mask = the forward output, `packed` = the data-gradient pack, relu = 0).  chunk must divide 16; Cp in {144, 112, 64, 32, 16}; other
- * shapes (e.g. Cp = 228, chunk 12 of the full configuration) take the general path: gather kernel + vmg_conv_fwd. */
-int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, int BT, int H, int W,
-                    int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream);
+ * shapes (e.g. Cp = 228, chunk 12 of the full configuration) take the general path: gather kernel + vmg_conv_fwd.
+ * tok_out (may be null): the token matrix the GEMM multiplied, (vmg_morphfc_token_rows(...), Cp) bf16, rows = (group, k) in the reference's
+ * order, after the mask / scale -- the operands of the weight gradient dW = dpre_tokens^T x_tokens (forward call: tokens of x; data-gradient
+ * call: tokens of dy * relu'(y) * in_scale), written by the lanes that hold them as MFMA fragments: no gather pass for the weight gradient. */
+int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, void* tok_out,
+                    int BT, int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream);
+int64_t vmg_morphfc_token_rows(int axis, int chunk, int BT, int H, int W);
 
 /* ---- 3-D shifted-window attention (reference: models/swin_3d.py:167-252 rWindowAttention.attention, :55-118 window partition / mask, :772-832 block) ----
  * q (B, D, H, W, C) and kv (B, D, H, W, 2C; k then v) are the outputs of the q / kv Linears on the UN-partitioned feature map; window partition

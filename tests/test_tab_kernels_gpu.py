@@ -131,6 +131,30 @@ def test_fused_morphfc_branch_fwd_bwd(cfg, axis):
     assert float((bd.grad.cpu() - wg[2]).abs().max()) <= 3e-2 * max(1e-6, float(wg[2].abs().max()))
 
 
+@pytest.mark.parametrize("cfg", [(144, 8, 24, 20), (112, 8, 13, 16), (32, 16, 40, 24)])
+@pytest.mark.parametrize("axis", ["h", "w"])
+def test_fused_morphfc_token_side_outputs(cfg, axis):
+    """The token matrices the fused kernel writes next to its output are exactly the reference's reshuffle (FH.morph_tokens, checked against the
+    oracle elsewhere) of x in the forward call and of dy * relu'(y) / Cp in the data-gradient call; rows past the last group are zero."""
+    import math
+    from oracle import recipe as R
+    from vmg_amd import functional as FH, kernels as K, hip
+    C, chunk, H, W = cfg
+    Cp = int(math.ceil(C / chunk)) * chunk
+    dt = torch.bfloat16
+    x = R.seeded((1, 3, H, W, C), 210).cuda().to(dt)
+    dy = R.seeded((1, 3, H, W, C), 211).cuda().to(dt)
+    w = R.seeded((Cp, Cp), 212, Cp ** -0.5).cuda()
+    nct = (Cp + 15) // 16
+    y, tok = K.morphfc_forward(x, axis, chunk, Cp, FH.packed(w, dt, "fwd", [Cp], tiles=nct), None, True, 1.0, 1.0 / Cp, want_tokens=True)
+    ref = FH.morph_tokens(x, axis, chunk, Cp).reshape(-1, Cp)
+    assert tok.shape[0] >= ref.shape[0] and tok.shape[0] % 16 == 0
+    assert torch.equal(tok[:ref.shape[0]], ref) and not bool(tok[ref.shape[0]:].any())
+    _, dtok = K.morphfc_forward(dy, axis, chunk, Cp, FH.packed(w, dt, "dgrad", None, 0, Cp, tiles=nct), None, False, 1.0 / Cp, 1.0, mask=y, want_tokens=True)
+    dref = FH.morph_tokens(K.act_backward(dy, y, hip.ACT_RELU, 0.0, 1.0 / Cp), axis, chunk, Cp).reshape(-1, Cp)
+    assert torch.equal(dtok[:dref.shape[0]], dref) and not bool(dtok[dref.shape[0]:].any())
+
+
 @pytest.mark.parametrize("case", [(28, 144, 18, 144, "relu", 0), (4, 144, 36, 432, "gelu", 1), (7, 448, 56, 448, "relu", 0), (1, 112, 28, 336, "gelu", 1),
                                   (70, 32, 4, 96, "gelu", 1)])
 def test_se_mlp_fwd_bwd_matches_torch(case):

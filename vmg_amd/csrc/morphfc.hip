@@ -24,6 +24,7 @@ struct MorphK {
   const bf16* x;      // (BT, H, W, C)
   const bf16* mask;   // data-gradient form: the forward output h (same layout); x is multiplied by (mask > 0) * in_scale
   bf16* out;          // (BT, H, W, C)
+  bf16* tok_out;      // null, or (ntiles * 16, Cp): the token matrix the GEMM multiplies (after the mask / scale), for the weight gradient
   const char* wpack;  // vmg_conv_pack image, ks = 1, one source of Cp channels, NCT tiles
   const float* bias;  // (Cp) or null
   int BT, H, W, C, Cp, chunk, S, axis;  // axis 0: groups along H, 1: along W
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
           if (++s == S) { s = 0; ++p; }
         }
       }
+      // the lane's fragment = features 32 ks + 8 kq .. + 7 of token (tile, tok): one 16-byte vector of the token matrix
+      if (a.tok_out && 32 * ks + 8 * kq < a.Cp) *reinterpret_cast<bf16x8*>(a.tok_out + (tile * 16 + tok) * a.Cp + 32 * ks + 8 * kq) = tf;
       const char* wk = wl + (ks >> 1) * a.ss + (ks & 1) * KSB + kq * (COB * 16) + tok * 16;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -193,17 +196,25 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
 // the stage stride vmg_conv_pack uses for ks = 1 (conv_igemm.hip: stage_stride(1, ntb, 16))
 static int morph_stage_stride(int nct) { return (2 * 4 * nct * 16 * 16 + 4095) / 4096 * 4096; }
 
-extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, int BT,
-                               int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream) {
+extern "C" int64_t vmg_morphfc_token_rows(int axis, int chunk, int BT, int H, int W) {
+  if (chunk <= 0 || 16 % chunk || BT <= 0 || H <= 0 || W <= 0) return -1;
+  const int len = axis == 0 ? H : W, lines = axis == 0 ? W : H;
+  const long long ngroups = (long long)BT * lines * cdiv(len, chunk);
+  return cdiv64(ngroups, 16 / chunk) * 16;
+}
+
+extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, void* tok_out,
+                               int BT, int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream) {
   VMG_CHECK(x && packed && out && BT > 0 && H > 0 && W > 0, "morphfc: bad arguments");
   VMG_CHECK(axis == 0 || axis == 1, "morphfc: axis 0 (H) or 1 (W)");
   VMG_CHECK(chunk > 0 && 16 % chunk == 0 && Cp % chunk == 0 && Cp >= C && C % 8 == 0, "morphfc: chunk must divide 16 and Cp; C a multiple of 8");
-  VMG_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)relu_mask) % 16 == 0, "morphfc: pointers must be 16-byte aligned");
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)relu_mask | (uintptr_t)tok_out) % 16 == 0, "morphfc: pointers must be 16-byte aligned");
+  VMG_CHECK(!tok_out || Cp % 8 == 0, "morphfc: the token output needs Cp to be a multiple of 8");
   const int nk = (Cp + 31) / 32, nct = (Cp + 15) / 16;
   VMG_CHECK(cout_tiles == nct, "morphfc: the pack must hold all %d output tiles in one block (cout_tiles = %d given)", nct, cout_tiles);
   MorphK k;
   memset(&k, 0, sizeof(k));
-  k.x = (const bf16*)x; k.mask = (const bf16*)relu_mask; k.out = (bf16*)out; k.wpack = (const char*)packed; k.bias = bias;
+  k.x = (const bf16*)x; k.mask = (const bf16*)relu_mask; k.out = (bf16*)out; k.tok_out = (bf16*)tok_out; k.wpack = (const char*)packed; k.bias = bias;
   k.BT = BT; k.H = H; k.W = W; k.C = C; k.Cp = Cp; k.chunk = chunk; k.S = Cp / chunk; k.axis = axis;
   const int len = axis == 0 ? H : W, lines = axis == 0 ? W : H;
   k.gpl = cdiv(len, chunk);

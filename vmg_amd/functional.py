@@ -761,14 +761,17 @@ def morph_untokens(t: torch.Tensor, axis: str, chunk: int, Cp: int, H: int, W: i
 class _MorphLinear(_Fn):
     """One MorphFC branch: relu(tokens(x) W^T + b) / Cp back in pixel layout (models/function.py:763-772, 776-785) as ONE kernel with the
     token reshuffle in the GEMM's addressing (vmg_morphfc_fwd).  Backward: the data gradient is the same kernel on (dy * relu'(y) / Cp)
-    with the transposed weight; only the weight gradient still needs the two token matrices (gathered here, summed by the batched
-    Linear weight-gradient GEMM)."""
+    with the transposed weight; the weight gradient's two token matrices are side outputs of those two launches (the lanes write the
+    MFMA fragments they hold), summed by the batched Linear weight-gradient GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, axis, chunk, Cp):
         x = x.contiguous()
         nct = (Cp + 15) // 16
-        y = K.morphfc_forward(x, axis, chunk, Cp, packed(weight, x.dtype, "fwd", [Cp], tiles=nct), bias, True, 1.0, 1.0 / Cp)
+        need_w = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        # the kernel writes the token matrix it multiplies as a side output: the weight gradient's x operand without a gather pass
+        ctx.tok_mode = bool(need_w and ctx.needs_input_grad[0] and Cp % 8 == 0)
+        y, tok = K.morphfc_forward(x, axis, chunk, Cp, packed(weight, x.dtype, "fwd", [Cp], tiles=nct), bias, True, 1.0, 1.0 / Cp, want_tokens=ctx.tok_mode)
         ctx.cfg = (axis, chunk, Cp)
         ctx.has_bias = bias is not None
         ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[1] and \
@@ -776,22 +779,27 @@ class _MorphLinear(_Fn):
         if ctx.defer:
             ctx.gen = DEFERRED.note_use(weight, bias)
             ctx.bias_ref = bias
-        ctx.save_for_backward(x, y, weight)
+        ctx.save_for_backward(tok if ctx.tok_mode else x, y, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight = ctx.saved_tensors
+        x, y, weight = ctx.saved_tensors  # (x: the token matrix in tok_mode)
         axis, chunk, Cp = ctx.cfg
         dy = dy.contiguous()
         nct = (Cp + 15) // 16
-        dx = None
+        dx = dpre = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
-            dx = K.morphfc_forward(dy, axis, chunk, Cp, packed(weight, dy.dtype, "dgrad", None, 0, Cp, tiles=nct), None, False, 1.0 / Cp, 1.0, mask=y)
+            dx, dpre = K.morphfc_forward(dy, axis, chunk, Cp, packed(weight, dy.dtype, "dgrad", None, 0, Cp, tiles=nct), None, False, 1.0 / Cp, 1.0, mask=y,
+                                         want_tokens=ctx.tok_mode and need_w)
         d_w = d_b = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            tok = morph_tokens(x, axis, chunk, Cp)                                                    # (B,T,G,chunk,Cp)
-            dpre = morph_tokens(K.act_backward(dy, y, hip.ACT_RELU, 0.0, 1.0 / Cp), axis, chunk, Cp)
+        if need_w:
+            if ctx.tok_mode:
+                tok = x
+            else:
+                tok = morph_tokens(x, axis, chunk, Cp)                                                    # (B,T,G,chunk,Cp)
+                dpre = morph_tokens(K.act_backward(dy, y, hip.ACT_RELU, 0.0, 1.0 / Cp), axis, chunk, Cp)
             M = tok.numel() // Cp
             if ctx.defer:
                 DEFERRED.add(weight, ctx.bias_ref, [tok], [Cp], dpre, 1, 1, 1, M, gen=ctx.gen)

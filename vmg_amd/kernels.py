@@ -416,8 +416,9 @@ def morph_fused_ok(x: torch.Tensor, chunk: int, Cp: int) -> bool:
 
 
 def morphfc_forward(x: torch.Tensor, axis: str, chunk: int, Cp: int, pw: PackedConv, bias: Optional[torch.Tensor], relu: bool, in_scale: float,
-                    out_scale: float, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x (B,T,H,W,C) contiguous bf16 -> the branch output in the same layout (vmg_morphfc_fwd); mask: the data-gradient form."""
+                    out_scale: float, mask: Optional[torch.Tensor] = None, want_tokens: bool = False):
+    """x (B,T,H,W,C) contiguous bf16 -> the branch output in the same layout (vmg_morphfc_fwd); mask: the data-gradient form.  want_tokens:
+    also returns the token matrix (rows, Cp) the GEMM multiplied (the weight gradient's operand), else None."""
     hip.require_cuda(x, bias, mask)
     B, T, H, W, C = x.shape
     if not x.is_contiguous() or (mask is not None and (not mask.is_contiguous() or mask.shape != x.shape or mask.dtype != x.dtype)):
@@ -427,10 +428,17 @@ def morphfc_forward(x: torch.Tensor, axis: str, chunk: int, Cp: int, pw: PackedC
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cp or not bias.is_contiguous()):
         raise HipError("morphfc: bias must be contiguous fp32 of length Cp")
     out = torch.empty_like(x)
-    hip.check(hip.lib().vmg_morphfc_fwd(0 if axis == "h" else 1, chunk, x.data_ptr(), mask.data_ptr() if mask is not None else None, pw.buf.data_ptr(),
-                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), B * T, H, W, C, Cp, pw.cout_tiles, 1 if relu else 0,
-                                        in_scale, out_scale, hip.stream_ptr()), "vmg_morphfc_fwd")
-    return out
+    ax = 0 if axis == "h" else 1
+    tok = None
+    if want_tokens:
+        rows = hip.lib().vmg_morphfc_token_rows(ax, chunk, B * T, H, W)
+        if rows <= 0:
+            raise HipError("morphfc: bad token geometry")
+        tok = torch.empty((rows, Cp), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().vmg_morphfc_fwd(ax, chunk, x.data_ptr(), mask.data_ptr() if mask is not None else None, pw.buf.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), tok.data_ptr() if tok is not None else None,
+                                        B * T, H, W, C, Cp, pw.cout_tiles, 1 if relu else 0, in_scale, out_scale, hip.stream_ptr()), "vmg_morphfc_fwd")
+    return out, tok
 
 
 def _win3d_geom(q, kv, table, heads, wt):
