@@ -82,3 +82,36 @@ def test_ltam_attention_fwd_bwd(dtype, shape):
     for nm, a, b in zip(names, gg, wg):
         err = float((a.float().cpu() - b).abs().max())
         assert err <= gtol * max(1.0, float(b.abs().max())), f"{nm}: {err} vs scale {float(b.abs().max())}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ltam_grad_bank_sums_the_calls_that_share_a_key_frame(dtype):
+    """Key / value frames wrapped in functional.grad_bank: three attention calls (1, 2, 3 key-frames, as the recurrence issues them) scatter
+    their gradients into one accumulator per frame; the result equals autograd's sum of the per-call gradients, including a frame that
+    is also used outside the attention."""
+    R, O, C, FH = _mods()
+    n, h, w, c = 2, 12, 16, 32
+    mk = lambda seed: _q(R.seeded((n, h, w, c), seed), dtype).cuda().to(dtype)
+    frames_k, frames_v = [mk(301 + j) for j in range(3)], [mk(311 + j) for j in range(3)]
+    qs = [mk(321 + j) for j in range(3)]
+    gos = [mk(331 + j) for j in range(3)]
+    rpe0 = R.seeded((4, 4, 4), 341, 0.5).cuda()
+    decay = (1 - 2 ** (-5 - torch.arange(3, -1, -1, dtype=torch.float32))).cuda()
+
+    def run(banked):
+        ks = [f.clone().requires_grad_(True) for f in frames_k]
+        vs = [f.clone().requires_grad_(True) for f in frames_v]
+        rpe = rpe0.clone().requires_grad_(True)
+        kk = [FH.grad_bank(k) if banked else k for k in ks]
+        vv = [FH.grad_bank(v) if banked else v for v in vs]
+        total = (ks[0] * gos[0]).sum().float()  # a use of frame 0 outside the attention
+        for t in (1, 2, 3):
+            loc = C.int_locations(n, t, h, w, 350 + t).cuda()
+            out = FH.ltam_attention(qs[t - 1], kk[:t], vv[:t], loc, rpe, decay, 4, 2, 2, (c // 4) ** -0.5)
+            total = total + (out * gos[t - 1]).sum().float()
+        return torch.autograd.grad(total, ks + vs + [rpe])
+
+    a, b = run(True), run(False)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert float((x.float() - y.float()).abs().max()) <= tol * max(1.0, float(y.float().abs().max())), f"gradient {i}"

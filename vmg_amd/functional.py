@@ -1118,10 +1118,47 @@ def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
     return K.warp_nearest_planes(loc.detach(), flow.detach().contiguous())
 
 
+class _GradBank:
+    """Gradient accumulator of ONE key / value frame over all the trajectory-attention calls that attend to it (a key-frame of a 7-frame clip
+    is attended by up to 6 later frames): their backward kernels scatter into the same buffer with atomics, instead of each call zero-filling
+    buffers of its own that autograd then sums pairwise."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _Banked(_Fn):
+    """Identity.  Backward: what the attention calls scattered into the bank (+ the gradient of any other use of the output)."""
+
+    @staticmethod
+    def forward(ctx, x, bank):
+        ctx.bank = bank
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.bank.buf = ctx.bank.buf, None
+        if buf is None:
+            return g, None
+        return (buf if g is None else buf.add_(g)), None
+
+
+def grad_bank(x: torch.Tensor) -> torch.Tensor:
+    """x as a key / value frame of later ltam_attention calls: the same values; the calls' gradients w.r.t. it are summed in one accumulator."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    bank = _GradBank()
+    y = _Banked.apply(x, bank)
+    y._vmg_bank = bank
+    return y
+
+
 class _LTAM(_Fn):
     @staticmethod
     def forward(ctx, q, loc, rpe, decay_v, cfg, *kv):
-        heads, wh, ww, scale = cfg
+        heads, wh, ww, scale, banks = cfg
         t = len(kv) // 2
         keys = [x.contiguous() for x in kv[:t]]
         vals = [x.contiguous() for x in kv[t:]]
@@ -1136,18 +1173,29 @@ class _LTAM(_Fn):
 
     @staticmethod
     def backward(ctx, dout):
-        heads, wh, ww, scale = ctx.cfg
+        heads, wh, ww, scale, banks = ctx.cfg
         t = ctx.t
         q, loc, rpe, decay_v, out, lse = ctx.saved_tensors[:6]
         keys = list(ctx.saved_tensors[6:6 + t])
         vals = list(ctx.saved_tensors[6 + t:])
-        dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale)
-        return (dq, None, drpe, None, None, *dk, *dv)  # (already in q's dtype)
+        into = []
+        for i, b in enumerate(banks):
+            if b is None or not ctx.needs_input_grad[5 + i]:
+                into.append(None)
+                continue
+            if b.buf is None:
+                b.buf = torch.zeros_like(q)
+            into.append(b.buf)
+        dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale, dk_into=into[:t], dv_into=into[t:])
+        gkv = [None if into[i] is not None else g for i, g in enumerate(dk + dv)]  # (banked frames: their _Banked node hands the sum on)
+        return (dq, None, drpe, None, None, *gkv)  # (already in q's dtype)
 
 
 def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):
-    """LTAM_multi_head.forward_wins without the output projection (models/trajectory.py:683-774)."""
-    return _LTAM.apply(q, loc, rpe, decay_v, (heads, wh, ww, float(scale)), *keys, *vals)
+    """LTAM_multi_head.forward_wins without the output projection (models/trajectory.py:683-774).  keys / vals that went through grad_bank
+    get their gradients accumulated in place across calls."""
+    banks = tuple(getattr(x, "_vmg_bank", None) for x in list(keys) + list(vals))
+    return _LTAM.apply(q, loc, rpe, decay_v, (heads, wh, ww, float(scale), banks), *keys, *vals)
 
 
 # ---- 3-D shifted-window attention (models/swin_3d.py) --------------------------------------------------

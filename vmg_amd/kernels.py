@@ -745,15 +745,27 @@ def ltam_forward(q, keys, vals, loc, rpe, decay, heads, wh, ww, scale):
     return out, lse
 
 
-def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale):
+def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale, dk_into=None, dv_into=None):
+    """dq, dk[j], dv[j], drpe.  dk_into / dv_into: per key-frame an existing accumulator of q's shape and dtype to scatter into (the gradient of a
+    frame that several calls attend to is summed by the kernel's atomics, see functional.grad_bank), or None for a fresh zeroed one."""
     n, h, w, c = q.shape
     t = len(keys)
     dout = dout.contiguous()
     dq = torch.empty_like(q)
-    acc = torch.zeros((2 * t, n, h, w, c), dtype=q.dtype, device=q.device)  # (bf16: packed bf16 atomics -- no fp32 copy, no cast pass)
+    dk = list(dk_into) if dk_into is not None else [None] * t
+    dv = list(dv_into) if dv_into is not None else [None] * t
+    for a in dk + dv:
+        if a is not None and (a.shape != q.shape or a.dtype != q.dtype or not a.is_contiguous()):
+            raise HipError("ltam_backward: accumulators must be contiguous tensors of q's shape and dtype")
+    fresh = [i for i, a in enumerate(dk + dv) if a is None]
+    if fresh:  # ONE zero-fill for all new accumulators (bf16 tensors: packed bf16 atomics -- no fp32 copy, no cast pass)
+        acc = torch.zeros((len(fresh), n, h, w, c), dtype=q.dtype, device=q.device)
+        for slot, i in enumerate(fresh):
+            if i < t:
+                dk[i] = acc[slot]
+            else:
+                dv[i - t] = acc[slot]
     drpe = torch.zeros_like(rpe)
-    dk = [acc[j] for j in range(t)]
-    dv = [acc[t + j] for j in range(t)]
     hip.check(hip.lib().vmg_ltam_bwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
                                      decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
                                      drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")

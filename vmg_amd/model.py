@@ -384,9 +384,9 @@ class Trajectory_multi_head(nn.Module):
                 if j % s == 0:
                     loc = torch.cat([loc, ident], 1)
             feat = self.resblocks([cur, feat])
-            if j % s == 0:
-                k_state.append(feat)
-                k_in.append(cur)
+            if j % s == 0:  # (grad_bank: the later frames' attention backward calls sum their gradients w.r.t. this key-frame in one buffer)
+                k_state.append(FH.grad_bank(feat))
+                k_in.append(FH.grad_bank(cur))
             feats.append(feat)
         halves = [f.split(n, 0) for f in feats]  # step j: (backward sweep at frame t-1-j, forward sweep at frame j)
         back = torch.stack([hv[0] for hv in reversed(halves)], 0)  # (t, n, h, w, c), frame order
