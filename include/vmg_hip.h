@@ -334,7 +334,7 @@ double vmg_prof_null_interval_us(int reps, void* stream);
  * are the channels-last (BT, H, W, C) feature maps, no token tensor exists.  axis 0 mixes along H, 1 along W.  `packed`: vmg_conv_pack image of
  * the (Cp, Cp) weight (ks = 1, one source of Cp channels, cout_tiles = ceil(Cp / 16)); the caller packs AFTER applying the retention decay
  * W <- W * Gamma (function.py:766-768).  relu_mask (may be null): the data-gradient form -- x is multiplied by (relu_mask > 0) * in_scale on the way
- * in (relu_mask = the forward output, `packed` = the data-gradient pack, relu = 0).  chunk must divide 16; Cp in {144, 112, 64, 32, 16}; other
+ * in (relu_mask = the forward output, `packed` = the data-gradient pack, relu = 0).  chunk 8 or 16; Cp in {144, 112, 64, 32, 16}; other
  * shapes (e.g. Cp = 228, chunk 12 of the full configuration) take the general path: gather kernel + vmg_conv_fwd.
  * tok_out (may be null): the token matrix the GEMM multiplied, (vmg_morphfc_token_rows(...), Cp) bf16, rows = (group, k) in the reference's
  * order, after the mask / scale -- the operands of the weight gradient dW = dpre_tokens^T x_tokens (forward call: tokens of x; data-gradient

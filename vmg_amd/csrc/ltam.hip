@@ -64,7 +64,7 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 head-thr
 // without a source reads the zero vector) and all of a thread's loads are issued before the first LDS store: loads behind a per-lane
 // branch are each followed by s_waitcnt vmcnt(0), which serialised 4-5 gather latencies per tile and key-frame.
 typedef __attribute__((ext_vector_type(4))) unsigned int lt_u32x4;  // (a native vector: the HIP uint4 struct behind a pointer select goes through scratch)
-__device__ __attribute__((aligned(16))) const unsigned int g_ltam_zero[4] = {0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned int g_ltam_zero[4] = {0, 0, 0, 0};  // (not const: a constant-address-space pointer in the select turns the loads into flat_load)
 
 template <typename T, int D>
 struct RowCopy {

@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int MF_WAVES = 8;
+constexpr int MF_MAXK = 5;  // 16-byte vectors of ONE group's pixel block per lane: chunk * C/8 <= 320
+typedef __attribute__((ext_vector_type(4))) unsigned int mf_u32x4;  // (a native vector: the HIP uint4 struct behind a pointer select goes through scratch)
+__device__ __attribute__((aligned(16))) unsigned int g_mf_zero[4] = {0, 0, 0, 0};  // (not const: a constant-address-space pointer in the select turns the loads into flat_load)
 
 struct MorphK {
   const bf16* x;      // (BT, H, W, C)
@@ -68,36 +71,60 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
     s0[ks] = f0 - p0[ks] * S;
   }
   const int vpp = a.C >> 3;      // 16-byte vectors per pixel (C % 8 == 0)
-  const int nvec = 16 * vpp;     // vectors of a tile's pixel block
-  const int G = 16 / ch;         // groups per tile
-  const long long lines_len = a.axis == 0 ? a.H : a.W;
+  const int G = 16 / ch;         // groups per tile (1 or 2: the host admits chunk 8 and 16 here)
+  const int lines_len = a.axis == 0 ? a.H : a.W, lines = a.axis == 0 ? a.W : a.H;
+  const int pos_stride = a.axis == 0 ? a.W : 1;  // pixels between consecutive positions of a group
+  // per-lane constants of a group's copy: vector L = 64 k + lane of the [chunk pixels][vpp vectors] list (the same for every tile)
+  int lp[MF_MAXK], lv[MF_MAXK];
+#pragma unroll
+  for (int k = 0; k < MF_MAXK; ++k) {
+    const int L = 64 * k + lane;
+    const int p = (int)(((float)L + 0.5f) * (1.0f / (float)vpp));  // exact: L < 2^16
+    lp[k] = L < ch * vpp ? p : -1;
+    lv[k] = L - p * vpp;
+  }
+  const bf16* zsrc = reinterpret_cast<const bf16*>(g_mf_zero);
 
   for (long long tile = (long long)blockIdx.x * MF_WAVES + wave; tile < a.ntiles; tile += (long long)gridDim.x * MF_WAVES) {
-    // ---- 1. pixel block -> LDS (zero-filled padding)
-    for (int idx = lane; idx < nvec; idx += 64) {
-      const int pixl = idx / vpp, v = idx - pixl * vpp;
-      const int g = pixl / ch, p = pixl - g * ch;
-      const long long gg = tile * G + g;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (gg < a.ngroups) {
-        const int gi = (int)(gg % a.gpl);
-        long long r = gg / a.gpl;
-        const int line = (int)(r % (a.axis == 0 ? a.W : a.H));
-        const long long bt = r / (a.axis == 0 ? a.W : a.H);
-        const int pos = gi * ch + p;
-        if (pos < lines_len) {
-          const long long pix = a.axis == 0 ? (bt * a.H + pos) * a.W + line : (bt * a.H + line) * a.W + pos;
-          val = *reinterpret_cast<const uint4*>(a.x + pix * a.C + v * 8);
-          if (a.mask) {
-            const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + pix * a.C + v * 8);
-            bf16* e = reinterpret_cast<bf16*>(&val);
-            const bf16* m = reinterpret_cast<const bf16*>(&mv);
+    // ---- 1. pixel block -> LDS (zero-filled padding).  Group coordinates are wave-uniform; every load is UNCONDITIONAL (a lane outside
+    // the image reads the zero vector) and all of a tile's loads are issued before the first one is used: loads behind a per-lane branch
+    // are each followed by s_waitcnt vmcnt(0), which made a tile cost ten serialised memory latencies (46 us per launch at N = 114 688).
+    long long gbase[2];  // first pixel of the group, or -1
+    int gpos0[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = (float)m[j] > 0.f ? (bf16)((float)e[j] * a.in_scale) : (bf16)0.f;
-          }
-        }
+    for (int g = 0; g < 2; ++g) {
+      const unsigned gg = (unsigned)(tile * G + g);  // (the host checks ngroups < 2^31)
+      const unsigned gi = gg % (unsigned)a.gpl, r = gg / (unsigned)a.gpl;
+      const unsigned line = r % (unsigned)lines, bt = r / (unsigned)lines;
+      gpos0[g] = (int)gi * ch;
+      const long long first = a.axis == 0 ? ((long long)bt * a.H + gpos0[g]) * a.W + line : ((long long)bt * a.H + line) * a.W + gpos0[g];
+      gbase[g] = (g < G && tile * G + g < a.ngroups) ? first : -1;
+    }
+    mf_u32x4 rx[2][MF_MAXK], rm[2][MF_MAXK];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int k = 0; k < MF_MAXK; ++k) {
+        const bool ok = lp[k] >= 0 && gbase[g] >= 0 && gpos0[g] + lp[k] < lines_len;
+        const long long off = (gbase[g] + (long long)lp[k] * pos_stride) * a.C + lv[k] * 8;
+        rx[g][k] = *reinterpret_cast<const mf_u32x4*>(ok ? a.x + off : zsrc);
+        if (a.mask) rm[g][k] = *reinterpret_cast<const mf_u32x4*>(ok ? a.mask + off : zsrc);  // (wave-uniform branch)
       }
-      *reinterpret_cast<uint4*>(xblk + pixl * rowb + v * 16) = val;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int k = 0; k < MF_MAXK; ++k) {
+        mf_u32x4 val = rx[g][k];
+        if (a.mask) {
+          bf16x8 e = __builtin_bit_cast(bf16x8, val);
+          const bf16x8 m = __builtin_bit_cast(bf16x8, rm[g][k]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (float)m[j] > 0.f ? (bf16)((float)e[j] * a.in_scale) : (bf16)0.f;
+          val = __builtin_bit_cast(mf_u32x4, e);
+        }
+        if (lp[k] >= 0 && g < G) *reinterpret_cast<mf_u32x4*>(xblk + (g * ch + lp[k]) * rowb + lv[k] * 16) = val;
+      }
     }
     if (a.Cp > a.C) {  // padded channels read as zero
       const int padc = a.Cp - a.C;
@@ -174,19 +201,14 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
         }
       }
     }
-    for (int idx = lane; idx < nvec; idx += 64) {
-      const int pixl = idx / vpp, v = idx - pixl * vpp;
-      const int g = pixl / ch, p = pixl - g * ch;
-      const long long gg = tile * G + g;
-      if (gg >= a.ngroups) continue;
-      const int gi = (int)(gg % a.gpl);
-      long long r = gg / a.gpl;
-      const int line = (int)(r % (a.axis == 0 ? a.W : a.H));
-      const long long bt = r / (a.axis == 0 ? a.W : a.H);
-      const int pos = gi * ch + p;
-      if (pos >= lines_len) continue;
-      const long long pix = a.axis == 0 ? (bt * a.H + pos) * a.W + line : (bt * a.H + line) * a.W + pos;
-      *reinterpret_cast<uint4*>(a.out + pix * a.C + v * 8) = *reinterpret_cast<const uint4*>(oblk + pixl * rowb + v * 16);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int k = 0; k < MF_MAXK; ++k) {
+        if (lp[k] < 0 || gbase[g] < 0 || gpos0[g] + lp[k] >= lines_len) continue;
+        const long long off = (gbase[g] + (long long)lp[k] * pos_stride) * a.C + lv[k] * 8;
+        *reinterpret_cast<mf_u32x4*>(a.out + off) = *reinterpret_cast<const mf_u32x4*>(oblk + (g * ch + lp[k]) * rowb + lv[k] * 16);
+      }
     }
   }
 }
@@ -207,7 +229,8 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
                                int BT, int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream) {
   VMG_CHECK(x && packed && out && BT > 0 && H > 0 && W > 0, "morphfc: bad arguments");
   VMG_CHECK(axis == 0 || axis == 1, "morphfc: axis 0 (H) or 1 (W)");
-  VMG_CHECK(chunk > 0 && 16 % chunk == 0 && Cp % chunk == 0 && Cp >= C && C % 8 == 0, "morphfc: chunk must divide 16 and Cp; C a multiple of 8");
+  VMG_CHECK((chunk == 8 || chunk == 16) && Cp % chunk == 0 && Cp >= C && C % 8 == 0 && chunk * (C / 8) <= 64 * MF_MAXK,
+            "morphfc: chunk must be 8 or 16 and divide Cp; C a multiple of 8, at most %d", 64 * MF_MAXK * 8 / 16);
   VMG_CHECK(((uintptr_t)x | (uintptr_t)out | (uintptr_t)packed | (uintptr_t)relu_mask | (uintptr_t)tok_out) % 16 == 0, "morphfc: pointers must be 16-byte aligned");
   VMG_CHECK(!tok_out || Cp % 8 == 0, "morphfc: the token output needs Cp to be a multiple of 8");
   const int nk = (Cp + 31) / 32, nct = (Cp + 15) / 16;
@@ -219,6 +242,7 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
   const int len = axis == 0 ? H : W, lines = axis == 0 ? W : H;
   k.gpl = cdiv(len, chunk);
   k.ngroups = (long long)BT * lines * k.gpl;
+  VMG_CHECK(k.ngroups < (1LL << 31) - 2, "morphfc: too many groups");
   const int G = 16 / chunk;
   k.ntiles = cdiv64(k.ngroups, G);
   k.relu = relu; k.in_scale = in_scale; k.out_scale = out_scale;

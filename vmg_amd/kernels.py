@@ -411,8 +411,8 @@ MORPH_FUSED_CP = (144, 112, 64, 32, 16)
 
 
 def morph_fused_ok(x: torch.Tensor, chunk: int, Cp: int) -> bool:
-    """Shapes the fused MorphFC kernel (vmg_morphfc_fwd) covers: bf16, chunk dividing 16, Cp instantiated, C a multiple of 8."""
-    return x.dtype == torch.bfloat16 and 16 % chunk == 0 and Cp in MORPH_FUSED_CP and x.shape[-1] % 8 == 0 and Cp % chunk == 0
+    """Shapes the fused MorphFC kernel (vmg_morphfc_fwd) covers: bf16, chunk 8 or 16, Cp instantiated, C a multiple of 8."""
+    return x.dtype == torch.bfloat16 and chunk in (8, 16) and Cp in MORPH_FUSED_CP and x.shape[-1] % 8 == 0 and Cp % chunk == 0
 
 
 def morphfc_forward(x: torch.Tensor, axis: str, chunk: int, Cp: int, pw: PackedConv, bias: Optional[torch.Tensor], relu: bool, in_scale: float,
