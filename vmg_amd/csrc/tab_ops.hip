@@ -32,27 +32,40 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__
 #pragma unroll
   for (int e = 0; e < VN; ++e) s[e] = 0.f;
   if (roff < rpb) {
+    // FOUR rows per thread and iteration, every load unconditional (a row past the end re-reads the first one and is not added): one load in
+    // flight per thread left the kernel at 2.5 TB/s
     const long long base = (long long)g * R * C + VN * cp;
-    for (long long r = r0 + roff; r < r1; r += rpb) {
-      const long long o = base + r * C;
-      const Vec va = *reinterpret_cast<const Vec*>(a + o);
-      if (mode == 0) {
-        if (b && c3) {
-          const Vec vb = *reinterpret_cast<const Vec*>(b + o), vc = *reinterpret_cast<const Vec*>(c3 + o);
+    constexpr int U = 4;
+    for (long long r = r0 + roff; r < r1; r += (long long)U * rpb) {
+      Vec va[U], vb[U], vc[U];
+      bool ok[U];
 #pragma unroll
-          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) + to_f32(vb.v[e]) + to_f32(vc.v[e]);
-        } else if (b) {
-          const Vec vb = *reinterpret_cast<const Vec*>(b + o);
+      for (int u = 0; u < U; ++u) {
+        const long long rr = r + (long long)u * rpb;
+        ok[u] = rr < r1;
+        const long long o = base + (ok[u] ? rr : r) * C;
+        va[u] = *reinterpret_cast<const Vec*>(a + o);
+        if (b) vb[u] = *reinterpret_cast<const Vec*>(b + o);
+        if (c3) vc[u] = *reinterpret_cast<const Vec*>(c3 + o);
+      }
 #pragma unroll
-          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) + to_f32(vb.v[e]);
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        if (mode == 0) {
+          if (b && c3) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) s[e] += to_f32(va[u].v[e]) + to_f32(vb[u].v[e]) + to_f32(vc[u].v[e]);
+          } else if (b) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) s[e] += to_f32(va[u].v[e]) + to_f32(vb[u].v[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) s[e] += to_f32(va[u].v[e]);
+          }
         } else {
 #pragma unroll
-          for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]);
+          for (int e = 0; e < VN; ++e) s[e] += to_f32(va[u].v[e]) * to_f32(vb[u].v[e]);
         }
-      } else {
-        const Vec vb = *reinterpret_cast<const Vec*>(b + o);
-#pragma unroll
-        for (int e = 0; e < VN; ++e) s[e] += to_f32(va.v[e]) * to_f32(vb.v[e]);
       }
     }
   }

@@ -113,18 +113,22 @@ __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restr
       for (int c = 2 * lane; c < C; c += 128) {  // (C is even: the host checks)
         const wp_bf16x2 gp = *reinterpret_cast<const wp_bf16x2*>(dy + pix * C + c);
         const float g0 = (float)gp[0], g1 = (float)gp[1];
-        auto corner = [&](long long o, float wgt, float sx, float sy) __attribute__((always_inline)) {
+        // the four corner reads are unconditional and issued together (a corner outside the image re-reads this pixel's own x and is dropped):
+        // loads behind a branch are waited for one by one
+        const long long own = pix * C;
+        const wp_bf16x2 xnw = *reinterpret_cast<const wp_bf16x2*>(x + (vnw ? onw : own) + c), xne = *reinterpret_cast<const wp_bf16x2*>(x + (vne ? one : own) + c);
+        const wp_bf16x2 xsw = *reinterpret_cast<const wp_bf16x2*>(x + (vsw ? osw : own) + c), xse = *reinterpret_cast<const wp_bf16x2*>(x + (vse ? ose : own) + c);
+        auto corner = [&](long long o, float wgt, float sx, float sy, wp_bf16x2 xp) __attribute__((always_inline)) {
           const wp_bf16x2 a = {(__bf16)(g0 * wgt), (__bf16)(g1 * wgt)};
           __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr)(dx_acc + o + c), __builtin_bit_cast(wp_s16x2, a));
-          const wp_bf16x2 xp = *reinterpret_cast<const wp_bf16x2*>(x + o + c);
           const float xv = (float)xp[0] * g0 + (float)xp[1] * g1;
           gix += xv * sx;
           giy += xv * sy;
         };
-        if (vnw) corner(onw, wnw, -(1.f - ty), -(1.f - tx));
-        if (vne) corner(one, wne, (1.f - ty), -tx);
-        if (vsw) corner(osw, wsw, -ty, (1.f - tx));
-        if (vse) corner(ose, wse, ty, tx);
+        if (vnw) corner(onw, wnw, -(1.f - ty), -(1.f - tx), xnw);
+        if (vne) corner(one, wne, (1.f - ty), -tx, xne);
+        if (vsw) corner(osw, wsw, -ty, (1.f - tx), xsw);
+        if (vse) corner(ose, wse, ty, tx, xse);
       }
     } else {
       for (int c = lane; c < C; c += 64) {
