@@ -548,6 +548,46 @@ def test_pixel_unshuffle_actgrad_one_pass(dtype, act):
         assert torch.equal(got, two)
 
 
+def test_pixel_shuffle_conv_on_the_weight_streaming_kernel():
+    """functional.conv2d(pixel_shuffle=True) for a conv the weight-streaming kernel covers (upconv1: 144 -> 576) = that kernel + the vectorised
+    depth-to-space pass; output and gradients against the kernel with the fused shuffle store (USE_WS off) and the oracle."""
+    hip, K, O, R = _setup()
+    from vmg_amd import functional as FH
+    N, H, W, C = 2, 16, 24, 144
+    dt = torch.bfloat16
+    x0 = _q(R.seeded((N, H, W, C), 501), dt)
+    w0 = _q(R.seeded((4 * C, C, 3, 3), 502, (9 * C) ** -0.5), dt)
+    b0 = R.seeded((4 * C,), 503, 0.1)
+    go = _q(R.seeded((N, 2 * H, 2 * W, C), 504), dt)
+    want = F.leaky_relu(O.pixel_shuffle_nhwc(O.conv_nhwc(x0, w0, b0, 1)), 0.1)
+    res = []
+    for ws in (True, False):
+        FH.USE_WS = ws
+        try:
+            x = x0.cuda().to(dt).requires_grad_(True)
+            w, b = torch.nn.Parameter(w0.cuda()), torch.nn.Parameter(b0.cuda())
+            y = FH.conv2d([x], w, b, N, H, W, ks=3, act=hip.ACT_LRELU, slope=0.1, pixel_shuffle=True)
+            g = torch.autograd.grad(y, [x, w, b], go.cuda().to(dt))
+            res.append((y.detach(), g))
+        finally:
+            FH.USE_WS = True
+    _cmp(res[0][0], want, dt, "pixel shuffle conv on the ws kernel")
+    assert float((res[0][0].float() - res[1][0].float()).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))
+    for a, b_ in zip(res[0][1], res[1][1]):
+        assert float((a.float() - b_.float()).abs().max()) <= 2e-2 * max(1.0, float(b_.float().abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pixel_shuffle_vector_kernel(dtype):
+    hip, K, O, R = _setup()
+    N, H, W, c = 2, 5, 7, 24
+    x = R.seeded((N, H, W, 4 * c), 511).to(dtype)
+    got = K.pixel_shuffle(x.cuda(), N, H, W)
+    want = F.pixel_shuffle(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(K.pixel_unshuffle(got, N, H, W).cpu(), x)
+
+
 def test_repack_all_equals_individual_packs():
     """The one-launch repack plan (vmg_pack_entry / vmg_pack_run) rebuilds exactly the bytes the single pack calls produce: forward and
     data-gradient packs, both layouts, fp32 and bf16, 1x1 / 3x3 / 7x7, a channel slice, after an 'optimizer step' that rewrote the weights."""

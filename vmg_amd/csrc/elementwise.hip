@@ -66,6 +66,39 @@ __global__ void pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ o
   }
 }
 
+// depth-to-space with 16-byte vectors (c a multiple of the vector): a thread reads the 4V consecutive low-res channels that hold V channels of
+// the four sub-pixels and writes one vector to each of them.
+template <typename T>
+__global__ void pixel_shuffle_vec_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int c) {
+  constexpr int V = Vec<T>::N;
+  const int cv = c / V;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv);
+    long long p = i / cv;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    const T* lo = in + (((long long)n * H + y) * W + x) * (4LL * c) + 4LL * v * V;
+    Vec<T> g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Vec<T> t = reinterpret_cast<const Vec<T>*>(lo)[k];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int q = k * V + j;  // low-res channel 4 * (v*V + q/4) + q%4
+        g[q & 3].v[q >> 2] = t.v[j];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long hi = (((long long)n * 2 * H + 2 * y + (r >> 1)) * (2 * W) + 2 * x + (r & 1)) * c + v * V;
+      *reinterpret_cast<Vec<T>*>(out + hi) = g[r];
+    }
+  }
+}
+
 // Backward of a conv with a PixelShuffle store and an activation: dpre[n, y, x, 4c + 2i + j] = dy[n, 2y + i, 2x + j, c] * alpha * act'(ref[same])
 // in ONE pass (was: depth-to-space of dy, of the saved output, then act_bwd: 7 tensor passes over the HR map instead of 3).  A thread
 // owns V consecutive channels of one low-res pixel group: four 16-byte loads per operand, four 16-byte stores of 4V consecutive channels.
@@ -370,6 +403,15 @@ extern "C" int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, in
   const long long total = (long long)N * H * W * c;
   const int blocks = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
   hipStream_t st = (hipStream_t)stream;
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  if (!to_depth && c % vn == 0 && ((uintptr_t)in | (uintptr_t)out) % 16 == 0) {
+    const long long tv = (long long)N * H * W * (c / vn);
+    const int bv = (int)(cdiv64(tv, 256) > 8192 ? 8192 : cdiv64(tv, 256));
+    if (dtype == VMG_BF16) hipLaunchKernelGGL(pixel_shuffle_vec_kernel<bf16>, dim3(bv), dim3(256), 0, st, (const bf16*)in, (bf16*)out, N, H, W, c);
+    else hipLaunchKernelGGL(pixel_shuffle_vec_kernel<float>, dim3(bv), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W, c);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == VMG_BF16) {
     if (to_depth) hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, N, H, W, c);
     else hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, N, H, W, c);

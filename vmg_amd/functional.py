@@ -398,10 +398,19 @@ class _Conv2d(_Fn):
         src_ch = [s.shape[-1] for s in srcs]
         srcs_p = [_pad_channels(s) for s in srcs]
         tiles, mt, deep = choose_tiling(N * H * W, weight.shape[0], ks, dt, src_ch, pixel_shuffle)
+        # a PixelShuffle conv the weight-streaming kernel covers (upconv1: 144 -> 576) runs there and is shuffled by a second, HBM-bound pass:
+        # 250 + 55 us against 579 us on the kernel with the fused shuffle store (M = 114 688)
+        ps_after = False
+        if pixel_shuffle and USE_WS and res is None:
+            t_ws = K.ws_eligible(weight.shape[0], ks, dt, [s.shape[-1] for s in srcs_p])
+            if t_ws:
+                ps_after, tiles, mt, deep = True, t_ws, 1, 3
         pw = packed(weight, dt, "fwd", src_ch, tiles=tiles, deep=deep)
         need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
         out, pre = K.conv_forward(srcs_p, pw, bias, N, H, W, act=act, slope=slope, alpha=alpha, res=res,
-                                  pixel_shuffle=pixel_shuffle, want_pre=need_pre, mt=mt, deep=deep)
+                                  pixel_shuffle=pixel_shuffle and not ps_after, want_pre=need_pre, mt=mt, deep=deep)
+        if ps_after:
+            out = K.pixel_shuffle(out, N, H, W)
         ctx.cfg = cfg
         ctx.src_ch = src_ch
         ctx.src_shapes = [tuple(t.shape) for t in srcs]
