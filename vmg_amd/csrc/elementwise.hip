@@ -151,6 +151,7 @@ __global__ void pixel_unshuffle_actgrad_kernel(const T* __restrict__ dy, const T
 // ----------------------------------------------------------------------------------------- LayerNorm
 // One row per group of G lanes (G = 16, 32 or 64 chosen from C); each lane keeps its vectors in registers.
 constexpr int LN_MAXV = 4;  // vectors per lane -> C <= 64 * 4 * 8 = 2048 (bf16), 1024 (fp32)
+constexpr int LN_SUB = 32;  // sub-accumulators of the backward's parameter gradients
 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, long long M, int C,
-                                                            const LnMap map, const T* __restrict__ add) {
+                                                            const LnMap map, const T* __restrict__ add, float* __restrict__ ws,
+                                                            unsigned int* __restrict__ counter) {
   // add (optional, contiguous rows): a gradient that reaches the same tensor by a skip connection; dx = add + LayerNorm backward, so the
   // sum does not cost a pass of its own (the TAB residuals: x feeds the norm AND the residual add)
   const int nvec = C / V;
@@ -345,25 +347,90 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
   }
   // parameter gradients: block-level sum in LDS, then one float atomic per channel per block
-  extern __shared__ float sm[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-  __syncthreads();
+#ifdef VMG_DIAG
+  if (dw == nullptr) return;  // (tools/bench_ln.py, VMG_LN_DBG=1: the kernel without its parameter-gradient tail)
+#endif
+  // (LDS float atomics from all 256 threads cost 12 us here: the row groups of a wave are summed with shuffles, the four waves through LDS)
+  extern __shared__ float smw[];  // [4 waves][2][C]
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int vi = gl + k * G;
-    if (vi < nvec) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        atomicAdd(&sm[vi * V + e], pdw[k][e]);
-        atomicAdd(&sm[C + vi * V + e], pdb[k][e]);
+    for (int e = 0; e < V; ++e) {
+      float a = pdw[k][e], b2 = pdb[k][e];
+#pragma unroll
+      for (int o = G; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        b2 += __shfl_xor(b2, o, 64);
+      }
+      const int vi = gl + k * G;
+      if ((threadIdx.x & 63) < G && vi < nvec) {
+        smw[(wv * 2) * C + vi * V + e] = a;
+        smw[(wv * 2 + 1) * C + vi * V + e] = b2;
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(&dw[i], sm[i]);
-    atomicAdd(&db[i], sm[C + i]);
+  float* sm = smw;  // [2][C]: the block's sums, in wave 0's slots
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = smw[i] + smw[2 * C + i] + smw[4 * C + i] + smw[6 * C + i];
+  __syncthreads();
+#ifdef VMG_DIAG
+  if (db == nullptr) return;  // (VMG_LN_DBG=2: with the block-level LDS sums, without the global ones)
+#endif
+  if (ws == nullptr) {  // (no workspace yet: one float atomic per channel and block -- 512 blocks queueing on 2C addresses cost 18 of 43 us at M = 114 688)
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(&dw[i], sm[i]);
+      atomicAdd(&db[i], sm[C + i]);
+    }
+    return;
   }
+  // LN_SUB sub-accumulators instead of one: block b adds (device-scope float atomics, performed at the memory side) to sub-accumulator
+  // b % LN_SUB -- 16 blocks per address instead of 512 -- and the LAST block to arrive collects them (atomic exchange with zero: read and
+  // re-arm in one), adds the sums to dw / db and resets the arrival counter.  Only atomics carry data between blocks, so no L2
+  // write-back / invalidate fence is needed (a __threadfence() per block made this kernel 7x slower): s_waitcnt vmcnt(0) before the
+  // ticket orders a block's adds before its arrival.
+  float* acc = ws + (size_t)(blockIdx.x % LN_SUB) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&acc[i], sm[i]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ unsigned int ticket;
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  const int nsub = min((int)gridDim.x, LN_SUB);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float v[LN_SUB];
+#pragma unroll
+    for (int sb = 0; sb < LN_SUB; ++sb) v[sb] = sb < nsub ? atomicExch(&ws[(size_t)sb * 2 * C + i], 0.f) : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int sb = 0; sb < LN_SUB; ++sb) t += v[sb];
+    if (i < C) dw[i] += t;
+    else db[i - C] += t;
+  }
+  if (threadIdx.x == 0) atomicExch(counter, 0u);  // ready for the next launch on this stream
+}
+
+// per-device workspace of the backward's sub-accumulators (zero between launches) + the arrival counter: allocated on the first call outside a
+// stream capture.  One per device: LayerNorm backward launches of a device must be stream-ordered (autograd runs them on the forward's stream).
+static float* g_ln_ws[VMG_MAX_DEVICES] = {};
+static unsigned int* g_ln_counter[VMG_MAX_DEVICES] = {};
+constexpr size_t LN_WS_FLOATS = (size_t)LN_SUB * 2 * 2048;  // C <= 64 lanes * LN_MAXV vectors * 8 = 2048
+static float* ln_workspace(hipStream_t st, unsigned int** counter) {
+  const int dev = vmg_current_device();
+  if (!g_ln_ws[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, LN_WS_FLOATS * 4 + 64) != hipSuccess || hipMemset(p, 0, LN_WS_FLOATS * 4 + 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_ln_ws[dev] = reinterpret_cast<float*>(p);
+    g_ln_counter[dev] = reinterpret_cast<unsigned int*>(p + LN_WS_FLOATS * 4);
+  }
+  *counter = g_ln_counter[dev];
+  return g_ln_ws[dev];
 }
 
 // lanes per row: the G in {16, 32, 64} that wastes the fewest lane slots (G * ceil(nvec / G)), the smaller G on a tie -- more rows per
@@ -468,10 +535,16 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
-  const int blocks = (int)(cdiv64(M, rows_per_block * 8) > 512 ? 512 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
-  const int lds = 2 * C * 4;
+  int blocks = (int)(cdiv64(M, rows_per_block * 8) > 512 ? 512 : cdiv64(M, rows_per_block * 8));  // (every block ends with 2C float atomics on the same addresses)
+#ifdef VMG_DIAG
+  { const char* e = getenv("VMG_LN_BLOCKS"); if (e && atoi(e) > 0) blocks = atoi(e); }
+  { const char* e = getenv("VMG_LN_DBG"); if (e && atoi(e) == 1) dw = nullptr; if (e && atoi(e) == 2) db = nullptr; }
+#endif
+  const int lds = 8 * C * 4;  // [4 waves][2][C] floats
   const int nv = (nvec + G - 1) / G;
-#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add)
+  unsigned int* counter = nullptr;
+  float* ws = (blocks > LN_SUB && C <= 2048) ? ln_workspace(st, &counter) : nullptr;  // (null: plain float atomics on dw / db)
+#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add, ws, counter)
 #define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
   if (G == 16) LN_LAUNCH_G(16);
   else if (G == 32) LN_LAUNCH_G(32);
