@@ -333,11 +333,12 @@ def test_conv_ksplit_pixel_shuffle():
 
 
 @pytest.mark.parametrize("tiles", [5, 3])
-@pytest.mark.parametrize("shape", [(1000, 144, 144), (114688, 144, 144), (4097, 144, 288), (300, 160, 48), (777, 64, 144), (50, 8, 16)])
+@pytest.mark.parametrize("shape", [(1000, 144, 144), (114688, 144, 144), (4097, 144, 288), (300, 160, 48), (777, 64, 144), (50, 8, 16), (4113, 288, 144), (70000, 288, 144), (333, 320, 96),
+                                   (500, 224, 112)])
 def test_linear_wave_autonomous_variant(shape, tiles):
     """The wave-autonomous 1x1 kernel (deep=4: weights resident in registers, 16-row tiles through wave-private LDS) against
-    torch: ragged M, several tiles per wave, both block sizes, every 16-byte epilogue; shapes it does not cover (padded LDS
-    stride at 64 channels) silently take the general kernel.  Results must be identical run to run."""
+    torch: ragged M, several tiles per wave, both block sizes, every 16-byte epilogue, a 288-channel source that the pack splits into two
+    blocks (Mlp_cnn.fc2; tiles = 3 only); shapes it does not cover (padded LDS stride at 64 channels) silently take the general kernel.  Results must be identical run to run."""
     hip, K, O, R = _setup()
     dtype = torch.bfloat16
     M, Ci, Co = shape

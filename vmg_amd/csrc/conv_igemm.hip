@@ -794,10 +794,12 @@ __global__ __launch_bounds__(256, (NTB <= 3 ? 3 : 2)) void conv_ksplit_kernel(co
 // block of its output-channel block resident in registers (5 k-steps x NTB fragments), walks over consecutive 16-row tiles
 // of the (M, C) matrix, copies tile t+1 into a wave-private LDS buffer by LDS-DMA while it multiplies tile t, and runs the
 // 16-byte epilogue through a wave-private LDS patch.  No workgroup barrier anywhere; one counted s_waitcnt per tile.
-template <int NTB>
-__global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int ntiles, int tiles_per_wave) {
+template <int NTB, int NS = 1>
+__global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void linear_wres_kernel(const ConvK a, int ntiles, int tiles_per_wave) {
   using T = bf16;
-  constexpr int KS = 1, CB = 16, NK = 5, NDMA = 5;  // <= 160 channels = 5 k-steps; a 16-row tile = <= 320 vectors = 5 x 1 KiB
+  // NS = 1: one source of <= 160 channels = 5 k-steps; a 16-row tile = <= 320 vectors = 5 x 1 KiB.  NS = 2: a source of <= 320 channels that the
+  // pack splits into two equal blocks (Mlp_cnn.fc2: 288 = 2 x 144): 10 k-steps, the tile is still ONE dense list of 16 x (2 CH) vectors.
+  constexpr int KS = 1, CB = 16, NKS = 5, NK = NKS * NS, NDMA = NK;
   constexpr int COB = NTB * 16;
   constexpr int SS = stage_stride(KS, NTB, CB);
   constexpr int KSB = 4 * COB * CB;
@@ -810,8 +812,9 @@ __global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int 
   const int cb = blockIdx.y;
   char* xbuf = smem + wave * WAVE_LDS;
   char* patch = xbuf + 2 * XBUF;
-  const int pixb = a.src_pixb[0], CH = a.src_ch[0] >> 3, nb = (CH + 3) >> 2;  // pixb == ch * 2 (dense)
-  const int vpp = CH;                                                         // 16-byte vectors per row
+  const int CH = a.src_ch[0] >> 3, nb = (CH + 3) >> 2;  // chunks / k-steps per block
+  const int vpp = CH * NS;                               // 16-byte vectors per row
+  const int pixb = vpp * 16;                             // (dense rows in LDS)
   const long long ps_b = a.src_ps[0] * 2;
   const int t0 = (blockIdx.x * 4 + wave) * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
   if (t0 >= t1) return;  // (whole wave; nothing below synchronises across waves)
@@ -822,12 +825,13 @@ __global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int 
     const char* wlane = a.wpack + (long long)cb * a.nstages * SS + g * (COB * CB) + px * CB;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      const int kc = min(k, nb - 1);
-      const char* p = wlane + (long long)(kc >> 1) * SS + (kc & 1) * KSB;
+      const int sb = k / NKS, kk = k - sb * NKS;
+      const int kc = min(kk, nb - 1);
+      const char* p = wlane + (long long)(sb * a.src_nst[0] + (kc >> 1)) * SS + (kc & 1) * KSB;
 #pragma unroll
       for (int ct = 0; ct < NTB; ++ct) {
         wres[k][ct].load(p + ct * 16 * CB);
-        if (k >= nb) wres[k][ct].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (kk >= nb) wres[k][ct].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
   }
@@ -854,7 +858,10 @@ __global__ __launch_bounds__(256, 2) void linear_wres_kernel(const ConvK a, int 
   };
   int boff[NK];
 #pragma unroll
-  for (int k = 0; k < NK; ++k) boff[k] = px * pixb + min(4 * k + g, CH - 1) * CB;
+  for (int k = 0; k < NK; ++k) {
+    const int sb = k / NKS, kk = k - sb * NKS;
+    boff[k] = px * pixb + (sb * CH + min(4 * kk + g, CH - 1)) * CB;
+  }
 
   issue(t0, 0);
   int buf = 0;
@@ -1543,11 +1550,11 @@ int dispatch_ksplit(const ConvK& k, int ntb, int ncb, int halo_total, hipStream_
   return -1;
 }
 
-template <int NTB>
+template <int NTB, int NS = 1>
 int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
-  constexpr int WAVE_LDS = 2 * 5 * 1024 + ((EpiLds<NTB>::BYTES + 1023) & ~1023);
+  constexpr int WAVE_LDS = 2 * 5 * NS * 1024 + ((EpiLds<NTB>::BYTES + 1023) & ~1023);
   const int lds = 4 * WAVE_LDS;
-  auto fn = linear_wres_kernel<NTB>;
+  auto fn = linear_wres_kernel<NTB, NS>;
   static bool attr_set[VMG_MAX_DEVICES] = {};
   const int dev = vmg_current_device();
   if (!attr_set[dev]) {
@@ -1558,7 +1565,8 @@ int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
   const long long ntiles = cdiv64(k.M, 16);
   VMG_CHECK(ntiles > 0 && ntiles < (1ll << 31), "conv: bad tile count %lld", ntiles);
   // two workgroups per CU over all output-channel blocks; at least 4 tiles per wave so the resident weights pay off
-  long long waves = (long long)(2 * ncu / ncb > 0 ? 2 * ncu / ncb : 1) * 4;
+  constexpr int WG_PER_CU = NS == 1 ? 2 : 1;
+  long long waves = (long long)(WG_PER_CU * ncu / ncb > 0 ? WG_PER_CU * ncu / ncb : 1) * 4;
   long long tpw = cdiv64(ntiles, waves);
   if (tpw < 4) tpw = 4;
   const long long nwg = cdiv64(cdiv64(ntiles, tpw), 4);
@@ -1819,10 +1827,13 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     k.tiles_y = cdiv(d->H, 8);
     return ntb == 9 ? launch_ws<9>(k, ncb, st) : launch_ws<7>(k, ncb, st);
   }
-  if (d->deep == 4 && d->dtype == VMG_BF16 && d->ks == 1 && n == 1 && k.src_ch[0] <= 160 && k.src_pixb[0] == k.src_ch[0] * 2 && k.vec8 &&
-      (ntb == 3 || ntb == 5)) {
+  if (d->deep == 4 && d->dtype == VMG_BF16 && d->ks == 1 && k.vec8 && (ntb == 3 || ntb == 5)) {
     // (a hint: anything it does not cover -- padded LDS stride, several sources, unaligned rows -- takes the general kernel below)
-    return ntb == 3 ? launch_linear_wres<3>(k, ncb, st) : launch_linear_wres<5>(k, ncb, st);
+    if (n == 1 && k.src_ch[0] <= 160 && k.src_pixb[0] == k.src_ch[0] * 2) return ntb == 3 ? launch_linear_wres<3>(k, ncb, st) : launch_linear_wres<5>(k, ncb, st);
+    // one wide source that the pack split into two equal blocks (288 = 2 x 144)
+    if (n == 2 && ntb == 3 && d->nsrc == 1 && k.src_ch[0] == k.src_ch[1] && k.src_ch[0] <= 160 && k.src[1] == k.src[0] + k.src_ch[0] * 2 &&
+        k.src_nst[0] == k.src_nst[1])
+      return launch_linear_wres<3, 2>(k, ncb, st);
   }
   if (d->ks == 7) return d->dtype == VMG_BF16 ? dispatch_ks7<bf16>(k, ntb, ncb, st) : dispatch_ks7<float>(k, ntb, ncb, st);
   if (d->deep == 2) {

@@ -45,8 +45,13 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
             return t, 1, 3  # weight-streaming kernel: 128-pixel x 144/112-channel workgroups, the CU pulls the weights once
     if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
         return 3, 1, 2  # 288 (local_cnn): 151 us vs 247 us at 144 -> 288, M = 114 688; the 576-channel PixelShuffle convs were slower this way
-    if dtype == torch.bfloat16 and ks == 1 and cout == 144 and src_ch is not None and len(src_ch) == 1 and src_ch[0] == 144 and M >= 65536:
-        return 5, 1, 4  # the 144 -> 144 Linears of stage 0 (token mixers, proj): wave-autonomous kernel, 21 us vs 33 us at M = 114 688 (no gain at M = 32 768)
+    if dtype == torch.bfloat16 and ks == 1 and src_ch is not None and len(src_ch) == 1 and M >= 65536 and not pixel_shuffle:
+        if cout == 144 and src_ch[0] == 144:
+            return 5, 1, 4  # the 144 -> 144 Linears of stage 0 (token mixers, proj): wave-autonomous kernel, 21 us vs 33 us at M = 114 688 (no gain at M = 32 768)
+        if cout == 288 and src_ch[0] == 144:
+            return 5, 1, 4  # Mlp_cnn.fc2's data gradient: 39 us vs 66 us (tools/bench_linear.py)
+        if cout == 144 and src_ch[0] == 288:
+            return 3, 1, 4  # Mlp_cnn.fc2 (the 288-channel source as two blocks of the pack): 48 us vs 55 us
     return None, 1, 0
 
 
