@@ -277,16 +277,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // pre (G, Hd) = W1 m + b1;  out (G, Co) = sigmoid(W2 act(pre) + b2)  (mode 0)  or softmax over consecutive triples (mode 1).
 // One workgroup per pooled row; LDS: the row m (C floats) and act(pre) (Hd floats).
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
+__global__ __launch_bounds__(1024) void se_mlp_fwd_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pre,
                                                          float* __restrict__ out, int C, int Hd, int Co, int act1, int mode) {
   extern __shared__ float sm[];
   float* mrow = sm;       // C
   float* z1 = sm + C;     // Hd
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 256) mrow[c] = m[(long long)g * C + c];
+  // (16 waves: the hidden units are a chain of dependent L2 latencies per wave -- 36 units take 3 rounds instead of 9 with 4 waves)
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+  for (int c = tid; c < C; c += nt) mrow[c] = m[(long long)g * C + c];
   __syncthreads();
-  for (int j = wave; j < Hd; j += 4) {  // a wave per hidden unit: lanes stride over the C inputs (coalesced W1 row)
+  for (int j = wave; j < Hd; j += nw) {  // a wave per hidden unit: lanes stride over the C inputs (coalesced W1 row)
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += w1[(long long)j * C + c] * mrow[c];
     s = wave_sum(s) + (b1 ? b1[j] : 0.f);
@@ -294,20 +295,22 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   if (mode == 0) {
-    for (int o = tid; o < Co; o += 256) {
+    for (int o = tid; o < Co; o += nt) {
       float s = b2 ? b2[o] : 0.f;
       const float* wr = w2 + (long long)o * Hd;
+#pragma unroll 12
       for (int j = 0; j < Hd; ++j) s += wr[j] * z1[j];
       out[(long long)g * Co + o] = 1.f / (1.f + expf(-s));
     }
   } else {
-    for (int c = tid; c < Co / 3; c += 256) {
+    for (int c = tid; c < Co / 3; c += nt) {
       float z[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int o = 3 * c + k;
         float s = b2 ? b2[o] : 0.f;
         const float* wr = w2 + (long long)o * Hd;
+#pragma unroll 12
         for (int j = 0; j < Hd; ++j) s += wr[j] * z1[j];
         z[k] = s;
       }
@@ -321,22 +324,22 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
 
 // Backward, row part (one workgroup per pooled row): dz2 = d(out)/d(logits) applied to dout, dz1 = (dz2 W2) * act'(pre), dm = dm_scale * dz1 W1.
 // dz2 (G, Co) and dz1 (G, Hd) go to the workspace for the parameter-gradient kernel.
-__global__ __launch_bounds__(256) void se_mlp_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+__global__ __launch_bounds__(1024) void se_mlp_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                               const float* __restrict__ pre, const float* __restrict__ w1,
                                                               const float* __restrict__ w2, float* __restrict__ dm, float* __restrict__ ws, int G,
                                                               int C, int Hd, int Co, int act1, int mode, float dm_scale) {
   extern __shared__ float sm[];
   float* dz2 = sm;        // Co
   float* dz1 = sm + Co;   // Hd
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nw = nt >> 6;
   float* gz2 = ws + (long long)g * Co;
   float* gz1 = ws + (long long)G * Co + (long long)g * Hd;
   const float* orow = out + (long long)g * Co;
   const float* drow = dout + (long long)g * Co;
   if (mode == 0) {
-    for (int o = tid; o < Co; o += 256) { const float v = drow[o] * orow[o] * (1.f - orow[o]); dz2[o] = v; gz2[o] = v; }
+    for (int o = tid; o < Co; o += nt) { const float v = drow[o] * orow[o] * (1.f - orow[o]); dz2[o] = v; gz2[o] = v; }
   } else {
-    for (int c = tid; c < Co / 3; c += 256) {
+    for (int c = tid; c < Co / 3; c += nt) {
       const float a0 = orow[3 * c], a1 = orow[3 * c + 1], a2 = orow[3 * c + 2];
       const float d0 = drow[3 * c], d1 = drow[3 * c + 1], d2 = drow[3 * c + 2];
       const float sd = a0 * d0 + a1 * d1 + a2 * d2;
@@ -346,15 +349,16 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_rows_kernel(const float* __res
     }
   }
   __syncthreads();
-  for (int j = wave; j < Hd; j += 4) {  // lanes stride over the Co outputs (column j of W2: a gather, served by L2)
+  for (int j = wave; j < Hd; j += nw) {  // lanes stride over the Co outputs (column j of W2: a gather, served by L2)
     float s = 0.f;
     for (int o = lane; o < Co; o += 64) s += dz2[o] * w2[(long long)o * Hd + j];
     s = wave_sum(s) * se_dact(pre[(long long)g * Hd + j], act1);
     if (lane == 0) { dz1[j] = s; gz1[j] = s; }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += nt) {
     float s = 0.f;
+#pragma unroll 12
     for (int j = 0; j < Hd; ++j) s += dz1[j] * w1[(long long)j * C + c];
     dm[(long long)g * C + c] = s * dm_scale;
   }
@@ -395,7 +399,7 @@ extern "C" int vmg_se_mlp_fwd(const float* m, const float* w1, const float* b1, 
   VMG_CHECK(m && w1 && w2 && pre && out && G > 0 && C > 0 && Hd > 0 && Co > 0, "se_mlp_fwd: bad arguments");
   VMG_CHECK((act1 == 1 || act1 == 3) && (mode == 0 || (mode == 1 && Co % 3 == 0)), "se_mlp_fwd: act1 is ReLU (1) or GELU (3); mode 1 needs Co = 3 * channels");
   VMG_CHECK((C + Hd) * 4 <= 64 * 1024, "se_mlp_fwd: C + Hd too large");
-  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(G), dim3(256), (C + Hd) * 4, (hipStream_t)stream, m, w1, b1, w2, b2, pre, out, C, Hd, Co, act1, mode);
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(G), dim3(1024), (C + Hd) * 4, (hipStream_t)stream, m, w1, b1, w2, b2, pre, out, C, Hd, Co, act1, mode);
   VMG_LAUNCH_CHECK();
   return 0;
 }
@@ -406,7 +410,7 @@ extern "C" int vmg_se_mlp_bwd(const float* dout, const float* out, const float* 
   VMG_CHECK(dout && out && m && pre && w1 && w2 && dm && dw1 && db1 && dw2 && db2 && ws && G > 0 && C > 0 && Hd > 0 && Co > 0, "se_mlp_bwd: bad arguments");
   VMG_CHECK((act1 == 1 || act1 == 3) && (mode == 0 || (mode == 1 && Co % 3 == 0)), "se_mlp_bwd: act1 is ReLU (1) or GELU (3); mode 1 needs Co = 3 * channels");
   VMG_CHECK((Co + Hd) * 4 <= 64 * 1024, "se_mlp_bwd: Co + Hd too large");
-  hipLaunchKernelGGL(se_mlp_bwd_rows_kernel, dim3(G), dim3(256), (Co + Hd) * 4, (hipStream_t)stream, dout, out, pre, w1, w2, dm, ws, G, C, Hd, Co, act1,
+  hipLaunchKernelGGL(se_mlp_bwd_rows_kernel, dim3(G), dim3(1024), (Co + Hd) * 4, (hipStream_t)stream, dout, out, pre, w1, w2, dm, ws, G, C, Hd, Co, act1,
                      mode, dm_scale);
   VMG_LAUNCH_CHECK();
   const int total = Hd * C + Co * Hd + Hd + Co;
