@@ -273,6 +273,7 @@ int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, c
  *                        op 3 MIX_BWD  o_k = p0 * coef[g,c,k] + add[g,c]   (k = 0,1,2)
  *                        op 4 GATE_FWD o0 = (p0 + p1) * tanh(p1)
  *                        op 5 GATE_BWD p0 = dy, p1 = x, p2 = y:  o0 = dy*tanh(y);  o1 = dy*(tanh(y) + (x+y)*(1 - tanh(y)^2))
+ *                        op 7 SCALE    o0 = p0 * coef[g,c] * s   (gradient of the DropPath residual w.r.t. the dropped branch, function.py:1212-1217)
  * ---------------------------------------------------------------------------------------------- */
 int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode, float scale,
                      void* stream);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void group_reduce3_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6 };
+enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6, OP_SCALE = 7 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict__ p0, const T* __restrict__ p1, const T* __restrict__ p2,
@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict
       const V16<T> x = *reinterpret_cast<const V16<T>*>(p1 + off);
 #pragma unroll
       for (int e = 0; e < VN; ++e) r0.v[e] = from_f32<T>((to_f32(a.v[e]) * coef[gc + e] + to_f32(x.v[e])) * s);
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else if (op == OP_SCALE) {  // p0 * g * s, coef (G, C): the DropPath residual's gradient w.r.t. the dropped branch
+#pragma unroll
+      for (int e = 0; e < VN; ++e) r0.v[e] = from_f32<T>(to_f32(a.v[e]) * coef[gc + e] * s);
       *reinterpret_cast<V16<T>*>(o0 + off) = r0;
     } else if (op == OP_CA_BWD) {  // d_r = dy * s * g + add ; d_x = dy * s
 #pragma unroll
@@ -494,7 +498,7 @@ extern "C" int vmg_group_reduce3(int dtype, const void* a, const void* b0, const
 extern "C" int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add,
                                    float s, void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "tab_elementwise: bad dtype");
-  VMG_CHECK(op >= 0 && op <= 6 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
+  VMG_CHECK(op >= 0 && op <= 7 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
   const int vn = dtype == VMG_BF16 ? 8 : 4;
   VMG_CHECK(C % vn == 0, "tab_elementwise: C must be a multiple of %d", vn);
   const long long total = rows * (C / vn);

@@ -880,15 +880,14 @@ class _ResidualDropPath(_Fn):
     @staticmethod
     def forward(ctx, res, y, g, gb=None):
         out = K.tab_elementwise(K.OP_CA_FWD, y.contiguous(), res.contiguous(), coef=g, s=1.0, G=g.shape[0])
-        if gb is None:
-            gb = g.to(y.dtype)  # (B, C): cast once, here
-        ctx.save_for_backward(gb.reshape((g.shape[0],) + (1,) * (y.dim() - 2) + (g.shape[1],)))
+        ctx.save_for_backward(g)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (gb,) = ctx.saved_tensors
-        return dy, dy * gb, None, None
+        (g,) = ctx.saved_tensors  # (B, C) fp32; the product is rounded once, like dy * g.to(dtype) (g takes the values 0 and s / keep)
+        dy = dy.contiguous()
+        return dy, K.tab_elementwise(K.OP_SCALE, dy, coef=g.contiguous(), s=1.0, G=g.shape[0]), None, None
 
 
 class _DropPlan:
