@@ -526,7 +526,10 @@ class Mlp_encoder(nn.Module):
         hf, wf = int(np.ceil(H / r)) * r, int(np.ceil(W / r)) * r
         f = F.pad(f, (0, wf - W, 0, hf - H), mode="reflect")
         f = F.adaptive_avg_pool2d(f, (hf // r, wf // r))
-        f = F.interpolate(f, scale_factor=r, mode="nearest")[..., :H, :W].contiguous()
+        # nearest x r (an integer factor) = every mean repeated over its r x r block: expand + reshape, whose backward is a block sum
+        # (torch's upsample_nearest2d backward kernel took 72 us per call on these small maps)
+        n_, c_, hq, wq = f.shape
+        f = f[:, :, :, None, :, None].expand(n_, c_, hq, r, wq, r).reshape(n_, c_, hq * r, wq * r)[..., :H, :W].contiguous()
         return f.view(B, T, C, H, W)
 
     def forward(self, x, flow_forward=None, flow_backward=None):
