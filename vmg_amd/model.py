@@ -228,9 +228,12 @@ class Enhanced_MorphFCs_decay(nn.Module):
 
     def forward(self, x):
         B, T, H, W, C = x.shape
-        with torch.no_grad():  # T1: persistent, outside autograd, before the GEMM (function.py:766-768, 779-781)
-            self.mlp_h[0].weight.mul_(self.gamma_h)
-            self.mlp_w[0].weight.mul_(self.gamma_w)
+        if getattr(self, "_t1_done", False):  # (VMG.forward has applied this call's decay for all mixers at once, FH.decay_weights_and_repack)
+            self._t1_done = False
+        else:
+            with torch.no_grad():  # T1: persistent, outside autograd, before the GEMM (function.py:766-768, 779-781)
+                self.mlp_h[0].weight.mul_(self.gamma_h)
+                self.mlp_w[0].weight.mul_(self.gamma_w)
         # token reshuffle + Linear + ReLU + 1/Ch + inverse reshuffle: one kernel per branch where it is instantiated
         h = FH.morph_linear(x, self.mlp_h[0].weight, self.mlp_h[0].bias, "h", self.chunk_h, self.Ch)
         w = FH.morph_linear(x, self.mlp_w[0].weight, self.mlp_w[0].bias, "w", self.chunk_w, self.Cw)
@@ -737,6 +740,16 @@ class VMG(nn.Module):
                     m.recompute = self.recompute_chains
             self._recompute_applied = self.recompute_chains
         FH.DROP.begin(x.device, self.training)  # the DropPath masks of this pass in one draw (functional._DropPlan)
+        # T1 (SURVEY trap): every MorphFC mixer multiplies its mlp_h / mlp_w weights by Gamma at each forward call -- all of them here, in one
+        # launch, with their packs rebuilt in one more; each mixer then skips its own multiply for this call
+        mixers = self.__dict__.get("_morph_mixers")
+        if mixers is None:
+            mixers = self.__dict__["_morph_mixers"] = [m for m in self.modules() if isinstance(m, Enhanced_MorphFCs_decay)]
+        if mixers:
+            FH.decay_weights_and_repack([m.mlp_h[0].weight for m in mixers] + [m.mlp_w[0].weight for m in mixers],
+                                        [m.gamma_h for m in mixers] + [m.gamma_w for m in mixers])
+            for m in mixers:
+                m._t1_done = True
         if torch.is_grad_enabled():
             FH.DEFERRED.begin_forward()  # per-pass use counts of the deferred weight gradients (functional._DeferredWgrad)
         # the kernels take fp32 / the module's compute dtype; an enclosing torch.autocast (tools/Trainer.py:132-143) must not
