@@ -83,3 +83,32 @@ def test_vmg_bf16_tolerance(name):
     p = psnr(got[0], want[0])
     assert p >= 40.0, f"PSNR(bf16 hip, fp32 oracle) = {p}"
     assert abs(psnr(got[0], tgt) - psnr(want[0], tgt)) <= 0.05
+
+
+def test_batched_retention_decay_equals_the_per_module_decay():
+    """T1: VMG.forward applies the Gamma decay of all MorphFC mixers in one launch (functional.decay_weights_and_repack) and rebuilds their packs
+    in one more; three consecutive calls must give the same outputs and leave the same mlp_h / mlp_w weights as the module-by-module path
+    (an empty mixer list switches the batching off), bit for bit."""
+    from oracle import cases as C
+    from tests.util import build_product
+    case = C.CASES["vmg_tiny_few"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"].cuda().to(torch.bfloat16)
+    outs, weights = [], []
+    for batched in (True, False):
+        m = build_product(case["cfg"], torch.bfloat16)
+        m.load_state_dict(sd)
+        m.eval()
+        if not batched:
+            m.__dict__["_morph_mixers"] = []
+        with torch.no_grad():
+            ys = [m(x).float().clone() for _ in range(3)]
+        outs.append(ys)
+        weights.append({k: v.clone() for k, v in m.state_dict().items() if "mlp_h.0.weight" in k or "mlp_w.0.weight" in k})
+    assert weights[0] and weights[0].keys() == weights[1].keys()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for k in weights[0]:
+        assert torch.equal(weights[0][k], weights[1][k]), k
+    assert not torch.equal(outs[0][0], outs[0][2])  # (the decay is stateful: a later call sees smaller weights)
