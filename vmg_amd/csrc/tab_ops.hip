@@ -452,6 +452,9 @@ extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const v
   VMG_CHECK(a && out && G > 0 && R > 0 && C > 0 && (C & 1) == 0 && C <= 512, "group_reduce: bad arguments (C even, <= 512)");
   VMG_CHECK(mode == 0 || (mode == 1 && b), "group_reduce: mode 1 needs b");
   int chunks = (int)(1024 / G);
+#ifdef VMG_DIAG
+  { const char* e = getenv("VMG_GR_BLOCKS"); if (e && atoi(e) > 0) chunks = atoi(e) / G; }  // (tools/bench_group_reduce.py)
+#endif
   if (chunks < 1) chunks = 1;
   if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
   hipStream_t st = (hipStream_t)stream;
