@@ -52,6 +52,9 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
             return 5, 1, 4  # Mlp_cnn.fc2's data gradient: 39 us vs 66 us (tools/bench_linear.py)
         if cout == 144 and src_ch[0] == 288:
             return 3, 1, 4  # Mlp_cnn.fc2 (the 288-channel source as two blocks of the pack): 48 us vs 55 us
+    if dtype == torch.bfloat16 and ks == 3 and not pixel_shuffle and M >= (1 << 20) and src_ch is not None and len(src_ch) == 1 and \
+            (cout <= 16 or src_ch[0] <= 16):
+        return None, 2, 0  # conv_last (64 -> 3) and its data gradient (8 -> 64) on 1.8 M pixels: 18 MFMAs per wave and tile -- 128-pixel tiles halve the workgroup count
     return None, 1, 0
 
 
