@@ -266,7 +266,9 @@ int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, c
 /* ------------------------------------------------------------------------------------------------
  * TAB token-mixer tail (models/function.py:542-558 channel attention, :791-802 branch re-weighting + tanh gate).
  * Tensors are (G, R, C) channels-last views (G groups of R rows); per-(group, channel) quantities are fp32.
- *   vmg_group_reduce     mode 0: out[g,c] += scale * sum_r (a [+ b + c3])   mode 1: out[g,c] += scale * sum_r a*b   (out caller-zeroed)
+ *   vmg_group_reduce     mode 0: out[g,c] = scale * sum_r (a [+ b + c3])   mode 1: out[g,c] = scale * sum_r a*b.  Two launches, NO atomics:
+ *                        block partials go to the workspace ws (vmg_group_reduce_ws_bytes() bytes of device memory, reusable by the next
+ *                        call on the stream) and are added in a fixed order -- the same bits on every run
  *   vmg_tab_elementwise  op 0 CA_FWD   o0 = (p0 * coef[g,c] + p1) * s
  *                        op 1 CA_BWD   o0 = p0 * s * coef[g,c] + add[g,c];  o1 = p0 * s
  *                        op 2 MIX_FWD  o0 = p0*coef[g,c,0] + p1*coef[g,c,1] + p2*coef[g,c,2]
@@ -275,12 +277,13 @@ int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, c
  *                        op 5 GATE_BWD p0 = dy, p1 = x, p2 = y:  o0 = dy*tanh(y);  o1 = dy*(tanh(y) + (x+y)*(1 - tanh(y)^2))
  *                        op 7 SCALE    o0 = p0 * coef[g,c] * s   (gradient of the DropPath residual w.r.t. the dropped branch, function.py:1212-1217)
  * ---------------------------------------------------------------------------------------------- */
+int64_t vmg_group_reduce_ws_bytes(void);
 int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode, float scale,
-                     void* stream);
-/* out (G, C, 3) += scale * sum over the R rows of group g of a * {b0, b1, b2} (fp32, zero-initialised by the caller): the three branch sums of
- * the MorphFC re-weighting backward from one pass over the gradient (reference: models/function.py:791-793 through autograd). */
+                     float* ws, int64_t ws_bytes, void* stream);
+/* out (G, C, 3) = scale * sum over the R rows of group g of a * {b0, b1, b2} (fp32): the three branch sums of the MorphFC re-weighting
+ * backward from one pass over the gradient (reference: models/function.py:791-793 through autograd).  Same two-launch ordered scheme. */
 int vmg_group_reduce3(int dtype, const void* a, const void* b0, const void* b1, const void* b2, float* out, int G, int64_t R, int C, float scale,
-                      void* stream);
+                      float* ws, int64_t ws_bytes, void* stream);
 int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add, float s,
                         void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream);
 
@@ -288,8 +291,8 @@ int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const
  * Flow-guided sampling of the trajectory recurrence (models/trajectory.py:71-116 flow_warp, :329-333, :414-417).
  * flow: (N,H,W,2) fp32 pixel offsets (x then y); coordinates follow flow_warp + F.grid_sample(align_corners=True).
  *   vmg_warp_bilinear_fwd   out[n,y,x,:] = bilinear sample of x at (x + flow_x, y + flow_y), border padding.
- *   vmg_warp_bilinear_bwd   dx_acc ((N,H,W,C), the tensors' dtype, caller-zeroed) += scatter of dy (float atomics; bf16: packed bf16
- *                           atomics, C even); dflow (fp32, (N,H,W,2)) = d/dflow, every element written.
+ *   vmg_warp_bilinear_bwd   dx_acc ((N,H,W,C), ALWAYS fp32, caller-zeroed) += scatter of dy (float atomics, also for bf16 tensors -- the
+ *                           caller rounds the sums to bf16 once; C even for bf16); dflow (fp32, (N,H,W,2)) = d/dflow, every element written.
  *   vmg_warp_nearest_planes advects the tracked-location maps (N,K2,H,W) fp32 with nearest sampling, border padding.
  * ---------------------------------------------------------------------------------------------- */
 int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out, int N, int H, int W, int C, void* stream);
@@ -303,9 +306,9 @@ int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int
  *   q (n,h,w,c); keys[j], vals[j] (n,h,w,c) for key-frame j = 0 (oldest) .. t-1; loc (n,2t,h,w) fp32 tracked pixel
  *   coordinates (x plane then y plane per key-frame); rpe (heads, wh*ww, wh*ww) fp32; decay (heads) fp32.
  *   out (n,h,w,c); lse (n,h,w,heads) fp32 log-sum-exp, kept for the backward pass.
- * Backward: dq (n,h,w,c); dk_acc[j], dv_acc[j] (n,h,w,c) caller-zeroed accumulators OF THE TENSORS' DTYPE (gradients are scattered to
- * the gathered source pixels with atomics: float atomics for fp32, packed bf16 atomics for bf16); drpe (heads, wq, wq) fp32
- * accumulated.  heads must be 4.
+ * Backward: dq (n,h,w,c); dk_acc[j], dv_acc[j] (n,h,w,c) caller-zeroed FP32 accumulators for every tensor dtype (gradients are
+ * scattered to the gathered source pixels with float atomics; several calls may add into one accumulator; the caller rounds the
+ * finished sums to the tensors' dtype once); drpe (heads, wq, wq) fp32 accumulated.  heads must be 4.
  * ---------------------------------------------------------------------------------------------- */
 int vmg_ltam_fwd(int dtype, const void* q, const void* const* keys, const void* const* vals, const float* loc, const float* rpe,
                  const float* decay, void* out, float* lse, int n, int h, int w, int c, int heads, int wh, int ww, int t, float scale,
@@ -401,6 +404,13 @@ int vmg_tile_finalize(const float* E, const float* Wt, float* out_f32, unsigned 
  * lr, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t).  torch's update order and formula, no amsgrad. */
 int vmg_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2, float eps,
                    void* stream);
+
+/* ---- clip_grad_norm_ over a flat fp32 gradient buffer (reference: torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) as
+ * called in tools/Trainer.py:141-143, 166-167 when train.if_grad_clip is set) -------------------------------------------------
+ * g: n floats, 16-byte aligned; workspace: vmg_grad_clip_ws_bytes() bytes of device memory; norm_out (DEVICE, 2 floats): the total
+ * L2 norm and the applied coefficient min(1, max_norm / (norm + 1e-6)).  Two launches, fixed summation order (bit-reproducible). */
+int64_t vmg_grad_clip_ws_bytes(void);
+int vmg_grad_clip_norm(float* g, int64_t n, float max_norm, void* workspace, float* norm_out, void* stream);
 
 /* ---- Charbonnier + edge loss (reference: utils/loss.py:22-79, CharbonnierLoss(eps, if_aux_loss=True, aux_ratio)) ---------
  * x, y: (planes, H, W) fp32 images, planes = B*T*3.  fwd: a1 (planes, ceil(H/2), ceil(W/2)) scratch, ld (planes, H, W) = the

@@ -336,6 +336,62 @@ def _():
     return dict(inputs=lambda: {}, run=run, no_weights=True)
 
 
+# ---- the whole per-step learning-rate update (tools/Trainer.py:244-272) ------------------------------------
+LR_UPDATES = {
+    # pre_training = true (every shipped config): group 0 = SPyNet (lr 0 until flow_fix, then group 1's lr * pre_lr_ratio), group 1 = the rest
+    "flow_fix": dict(T_period=[40], restarts=None, weights=None, eta_min=1e-7, base=[0.0, 2e-4], flow_fix=5, pre_lr_ratio=0.125,
+                     warmup_iter=-1, reduced_iter=None, steps=20),
+    "warmup_reduce_restarts": dict(T_period=[10, 20, 30], restarts=[10, 30], weights=[1, 0.5], eta_min=1e-7, base=[0.0, 2e-4], flow_fix=3,
+                                   pre_lr_ratio=0.125, warmup_iter=4, reduced_iter=12, steps=40),
+}
+
+
+def oracle_lr_update(cfg):
+    """Restatement of Trainer.update_learning_rate (tools/Trainer.py:244-272) over the recursion of CosineAnnealingLR_Restart
+    (utils/lr_scheduler.py:17-33): the learning rates of the two groups after each call update_learning_rate(cur_iter), cur_iter = 0, 1, ..."""
+    import math
+    base = list(cfg["base"])
+    lr = list(base)                       # the scheduler's construction step leaves lr = initial_lr
+    restarts = cfg["restarts"] or [0]
+    weights = cfg["weights"] or [1]
+    T, eta = cfg["T_period"][0], cfg["eta_min"]
+    epoch = last_restart = 0
+    recover = False if cfg["reduced_iter"] is not None else None
+    past = None
+    rows = []
+    for it in range(cfg["steps"]):
+        if recover:
+            lr[1] = past
+        epoch += 1                        # scheduler.step()
+        if epoch in restarts:
+            i = restarts.index(epoch)
+            last_restart, T = epoch, cfg["T_period"][i + 1]
+            lr = [b * weights[i] for b in base]
+        elif (epoch - last_restart - 1 - T) % (2 * T) == 0:
+            lr = [l + (b - eta) * (1 - math.cos(math.pi / T)) / 2 for l, b in zip(lr, base)]
+        else:
+            f = (1 + math.cos(math.pi * (epoch - last_restart) / T)) / (1 + math.cos(math.pi * (epoch - last_restart - 1) / T))
+            lr = [f * (l - eta) + eta for l in lr]
+        if recover is not None:
+            if it >= cfg["reduced_iter"]:
+                past, recover = lr[1], True
+                lr[1] *= 0.5
+            else:
+                recover = False
+        lr[0] = base[0] if it <= cfg["flow_fix"] else lr[1] * cfg["pre_lr_ratio"]
+        if it < cfg["warmup_iter"]:
+            lr = [b / cfg["warmup_iter"] * it for b in base]
+        rows.append(list(lr))
+    return rows
+
+
+@case("lr_update")
+def _():
+    def run(sd, inp):
+        return [torch.tensor(oracle_lr_update(cfg), dtype=torch.float64).float() * 1e4 for cfg in LR_UPDATES.values()]
+    return dict(inputs=lambda: {}, run=run, no_weights=True)
+
+
 # ---- fixture I/O -------------------------------------------------------------------------------------
 def save_fixture(path: str, shapes: Dict[str, List[int]], outs: List[torch.Tensor]):
     arrs = {"shapes": np.frombuffer(json.dumps(shapes).encode(), dtype=np.uint8)}

@@ -190,6 +190,29 @@ def reference_side(name, case, mods):
                 sch.step()
             outs.append(torch.tensor(rows, dtype=torch.float64).float() * 1e4)
         return {}, outs
+    if name == "lr_update":
+        # the reference's own Trainer.update_learning_rate, called as an unbound method on a stub `self` (Trainer.__init__ builds a CUDA model
+        # and is not run) that holds a real AdamW with the reference's two pre_training groups and the reference's scheduler
+        import types
+        import tools.Trainer as TR
+        from . import cases as C
+        outs = []
+        for cfg in C.LR_UPDATES.values():
+            ps = [torch.nn.Parameter(torch.zeros(1)) for _ in cfg["base"]]
+            opt = torch.optim.AdamW([{"params": [p], "lr": b} for p, b in zip(ps, cfg["base"])], lr=2e-4)
+            sch = TR.CosineAnnealingLR_Restart(opt, cfg["T_period"], eta_min=cfg["eta_min"], restarts=cfg["restarts"], weights=cfg["weights"])
+            stub = types.SimpleNamespace(optimizer=opt, scheduler=sch, recover_flag=False if cfg["reduced_iter"] is not None else None,
+                                         rd_iter=cfg["reduced_iter"], train_configs={"pre_training": True, "pre_lr_ratio": cfg["pre_lr_ratio"]},
+                                         config={"network": {"flow_fix": cfg["flow_fix"]}})
+            stub._get_init_lr = types.MethodType(TR.Trainer._get_init_lr, stub)
+            stub._set_lr = types.MethodType(TR.Trainer._set_lr, stub)
+            rows = []
+            for it in range(cfg["steps"]):
+                opt.step()
+                TR.Trainer.update_learning_rate(stub, it, warmup_iter=cfg["warmup_iter"])
+                rows.append([g["lr"] for g in opt.param_groups])
+            outs.append(torch.tensor(rows, dtype=torch.float64).float() * 1e4)
+        return {}, outs
     if name.startswith("infer_"):
         # tools/Tester.py's window loops, called as unbound methods on a stub `self` (Tester.__init__ builds a model from a
         # checkpoint path and is not run); the third-party names its module imports come from oracle/_standins

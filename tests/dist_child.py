@@ -2,7 +2,9 @@
 
     python tests/dist_child.py <mode> <outdir>     (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment)
 
-Both ranks use GPU 0 and exchange gradients over gloo (a one-GPU box; the driver's multi-GPU runs use RCCL).
+All ranks use GPU 0.  Backend: VMG_DIST_BACKEND = 'gloo' (default; two ranks on a one-GPU box) or 'nccl' (= RCCL; ONE rank -- two
+ranks cannot share a device on RCCL -- with every collective still issued: communicator creation, broadcast, ReduceOp.AVG all-reduce on the
+side stream, stream waits).  VMG_DIST_CASE: the oracle case whose model runs (vmg_tiny_few; vmg_tiny_swin = with the 3-D window attention).
 mode 'reducer': vmg_amd.train.TrainStep (FlatAdamW + GradBucketReducer, deferred batched weight gradients).
 mode 'ddp'    : what tools/Trainer.py does -- torch DistributedDataParallel + autocast + GradScaler + clip_grad_norm_ + AdamW.
 Writes, per step, the state dict the step started from and the exchanged (averaged) gradients to <outdir>/rank<r>.pt."""
@@ -20,24 +22,30 @@ def main():
     mode, outdir = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("VMG_DIST_BACKEND", "gloo")
+    if backend == "nccl":
+        assert world == 1, "one RCCL rank per device"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import cases as C
     from oracle import recipe as R
     from tests.util import build_product
     from vmg_amd import functional as FH
     from vmg_amd.train import TrainStep
-    case = C.CASES["vmg_tiny_few"]
+    name = os.environ.get("VMG_DIST_CASE", "vmg_tiny_few")
+    case = C.CASES[name]
     cfg = case["cfg"]
-    shapes, _ = C.load_fixture(os.path.join(ROOT, "tests", "golden", "vmg_tiny_few.npz"))
+    shapes, _ = C.load_fixture(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
     sd = C.case_state_dict(case, shapes, seed=rank)  # different weights per rank on purpose: the wrap must broadcast rank 0's
     m = build_product(cfg, torch.float32)
     m.load_state_dict(sd)
     m.train()
-    x = R.synthetic_clip(1, 3, 64, 64, 60 + rank).cuda()
+    x = R.synthetic_clip(1, cfg.num_frames, 64, 64, 60 + rank).cuda()
     y = R.synthetic_target(x.cpu()).cuda()
     log = []
     if mode == "reducer":
-        step = TrainStep(m, lr=1e-4, distributed=True, bucket_bytes=16 << 10)  # tiny model: several buckets
+        step = TrainStep(m, lr=1e-4, distributed=True, bucket_bytes=16 << 10, single_rank_collectives=world == 1)  # tiny model: several buckets
         def hook(ts):
             log[-1]["grads"] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
         step.grad_hook = hook
@@ -45,6 +53,7 @@ def main():
             log.append({"state": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}})
             step(x[None][0], y)
         nb = len(step.reducer.buckets)
+        assert step.reducer.active and step.reducer.op_avg == (backend == "nccl")
     else:
         ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=False)
         spy = list(m.spynet.parameters())
@@ -66,7 +75,7 @@ def main():
             scaler.step(opt)
             scaler.update()
         nb = 0
-    torch.save({"log": log, "buckets": nb, "wgrad_mode": FH.DEFERRED.mode}, os.path.join(outdir, f"rank{rank}.pt"))
+    torch.save({"log": log, "buckets": nb, "wgrad_mode": FH.DEFERRED.mode, "backend": dist.get_backend()}, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _oracle_grads(sd, cfg, x, tgt):
+def _oracle_grads(sd, cfg, x, tgt, want_out=False):
     from oracle import recipe as R
     from oracle import vmg_oracle as O
     osd = {}
@@ -28,14 +28,18 @@ def _oracle_grads(sd, cfg, x, tgt):
     oout = O.vmg_forward(osd, cfg, x, mutate=False, call_index=0)
     oloss = (oout - tgt).square().mean()
     oloss.backward()
+    if want_out:
+        return osd, float(oloss), oout.detach()
     return osd, float(oloss)
 
 
 @pytest.mark.parametrize("mode", ["autograd", "deferred"])
-@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_tiny_swin", "vmg_tiny_multi"])
+@pytest.mark.parametrize("name", ["vmg_tiny_few", "vmg_tiny_swin", "vmg_tiny_multi", "vmg_reds_full"])
 def test_parameter_gradients_match_oracle_autograd(name, mode):
     """Both weight-gradient modes (functional.set_wgrad_mode): 'autograd' returns every weight gradient through autograd,
-    'deferred' batches them per parameter and writes .grad when backward() ends.  NO explicit flush in either."""
+    'deferred' batches them per parameter and writes .grad when backward() ends.  NO explicit flush in either.
+    vmg_reds_full = the full 7-stage VMG-REDS configuration (BASELINE configs[2]: C = 112 / 224 / 224 / 448, chunk 12 with padded
+    Ch = 228, grouped FFN convs with hidden widths 672 .. 2 688, MDSC skips, 15-block chains): its backward, fp32 strict."""
     from oracle import cases as C
     from oracle import recipe as R
     from oracle import vmg_oracle as O
@@ -83,7 +87,8 @@ def test_parameter_gradients_match_oracle_autograd(name, mode):
     print(f"{name}: worst relative gradient error {worst:.2e}")
 
 
-def test_bf16_whole_model_gradients_few_levels():
+@pytest.mark.parametrize("which", ["few_levels", "reds_full"])
+def test_bf16_whole_model_gradients(which):
     """The benchmarked configuration's backward: VMG-REDS-few_levels (144 channels, 15-block recurrent chains), T = 7, bf16
     activations, train mode with DropPath off, deferred batched weight gradients -- against the fp32 oracle's autograd on
     the same weights and clip.  Stated bf16 tolerance: per parameter tensor, relative L2 error <= 0.12 where the
@@ -93,8 +98,9 @@ def test_bf16_whole_model_gradients_few_levels():
     from oracle import recipe as R
     from tests.util import build_product
     from vmg_amd import functional as FH
-    cfg = C.cfg_reds_few(T=7)
-    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_reds_few_cfg1.npz"))
+    # 'reds_full': the same statement for the full 7-stage configuration (BASELINE configs[2]'s per-GPU shard, T = 7)
+    cfg = C.cfg_reds_few(T=7) if which == "few_levels" else C.cfg_reds_full(T=7)
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_reds_few_cfg1.npz" if which == "few_levels" else "vmg_reds_full.npz"))
     chunk_of, window_of = R.vmg_chunk_lookup(cfg)
     sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
     # reference-style initial scale for the convs of the 15-block chains keeps activations O(1) through 31 convs
@@ -125,7 +131,7 @@ def test_bf16_whole_model_gradients_few_levels():
             if rel > worst[0]:
                 worst = (rel, k)
     cos = dot / (gg ** 0.5 * ww ** 0.5)
-    print(f"bf16 few_levels gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}")
+    print(f"bf16 {which} gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}")
     assert cos >= 0.995, cos
     assert worst[0] <= 0.12, worst
 
@@ -155,3 +161,43 @@ def test_recompute_chains_gives_the_same_gradients():
     for k in res[0][1]:
         a, b = res[0][1][k], res[1][1][k]
         assert float((a - b).abs().max()) <= 2e-3 * max(float(a.abs().max()), 1e-3 * gmax), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_forward_is_bit_reproducible_and_gradients_repeat(dtype):
+    """Two fresh models, same weights, same clip.  The FORWARD pass contains no atomics (the pooled sums are ordered partial sums): outputs and
+    loss must be equal bit for bit.  The BACKWARD pass scatters the flow-warp / trajectory-attention gradients with fp32 float atomics and
+    sums LayerNorm / bias partials the same way: arrival-order rounding of fp32 sums (each rounded to bf16 once), not 8-bit running sums --
+    stated bound: per parameter tensor, max |g1 - g2| <= 2e-4 of the tensor's gradient scale (floor 1e-3 of the model's largest)."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from tests.util import build_product
+    from vmg_amd import functional as FH
+    case = C.CASES["vmg_tiny_few"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = R.synthetic_clip(2, 3, 64, 64, 47).cuda()
+    tgt = R.synthetic_target(x.cpu()).cuda()
+    runs = []
+    FH.set_wgrad_mode("deferred")
+    try:
+        for _ in range(2):
+            m = build_product(case["cfg"], dtype)
+            m.load_state_dict(sd)
+            m.train()
+            out = m(x)
+            loss = (out.float() - tgt).square().mean()
+            loss.backward()
+            runs.append((out.detach().clone(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    finally:
+        FH.set_wgrad_mode("autograd")
+    assert torch.equal(runs[0][0], runs[1][0]), "forward outputs differ between two identical runs"
+    assert runs[0][1] == runs[1][1]
+    gmax = max(float(g.abs().max()) for g in runs[0][2].values())
+    worst = 0.0
+    for k, a in runs[0][2].items():
+        b = runs[1][2][k]
+        e = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e <= 2e-4, f"{k}: gradients of two identical runs differ by {e:.2e} of their scale"
+    print(f"run-to-run gradient difference ({dtype}): {worst:.2e} of the gradient scale")

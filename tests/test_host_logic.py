@@ -166,3 +166,26 @@ def test_abi_argument_counts_match_the_header():
         args = args.strip()
         n = 0 if args in ("", "void") else args.count(",") + 1
         assert n == len(hip.SIGNATURES[name][1]), f"{name}: header has {n} parameters, hip.py binds {len(hip.SIGNATURES[name][1])}"
+
+
+def test_lr_schedule_matches_the_reference_update_learning_rate():
+    """vmg_amd.train.LRSchedule against the fixture the reference's own Trainer.update_learning_rate produced (oracle/gen_golden.py case
+    'lr_update': tools/Trainer.py:244-272 over utils/lr_scheduler.py -- the scheduler's recursion, SPyNet's flow_fix / pre_lr_ratio, warm-up,
+    the reduced_iter halving, restarts) and against the oracle's restatement."""
+    import numpy as np
+    from oracle import cases as C
+    from vmg_amd.train import LRSchedule
+    _, ref = C.load_fixture(os.path.join(ROOT, "tests", "golden", "lr_update.npz"))
+    for (name, cfg), r in zip(C.LR_UPDATES.items(), ref):
+        groups = [{"params": [], "lr": b} for b in cfg["base"]]
+        sch = LRSchedule(groups, cfg["T_period"], restarts=cfg["restarts"], weights=cfg["weights"], eta_min=cfg["eta_min"],
+                         warmup_iter=cfg["warmup_iter"], pre_training=True, flow_fix=cfg["flow_fix"], pre_lr_ratio=cfg["pre_lr_ratio"],
+                         reduced_iter=cfg["reduced_iter"])
+        rows = [sch.step(it) for it in range(cfg["steps"])]
+        want = np.asarray(C.oracle_lr_update(cfg))
+        assert np.abs(np.asarray(rows) - want).max() <= 1e-12, name
+        sub = C.subsample(torch.tensor(rows, dtype=torch.float64).float() * 1e4)
+        assert np.abs(sub - r["sub"]).max() <= 1e-5, name
+        if cfg["flow_fix"] + 1 < cfg["steps"] and cfg["warmup_iter"] <= cfg["flow_fix"] + 1:
+            it = cfg["flow_fix"] + 1
+            assert rows[it][0] == rows[it][1] * cfg["pre_lr_ratio"] and rows[cfg["flow_fix"]][0] == 0.0  # SPyNet wakes up right after flow_fix

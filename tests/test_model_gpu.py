@@ -109,6 +109,6 @@ def test_batched_retention_decay_equals_the_per_module_decay():
     assert weights[0] and weights[0].keys() == weights[1].keys()
     for k in weights[0]:
         assert torch.equal(weights[0][k], weights[1][k]), k  # (the decayed weights themselves: bit for bit)
-    for a, b in zip(outs[0], outs[1]):  # (outputs: up to the run-to-run noise of the pooled sums' float atomics, bf16)
-        assert float((a - b).abs().max()) <= 1e-2 * max(1.0, float(b.abs().max()))
+    for a, b in zip(outs[0], outs[1]):  # (outputs: bit for bit too -- the forward pass has no atomics, the pooled sums are ordered)
+        assert torch.equal(a, b)
     assert float((outs[0][0] - outs[0][2]).abs().max()) > 0  # (the decay is stateful: a later call sees smaller weights)

@@ -191,3 +191,88 @@ def test_swin_decoder_layer_fwd_bwd(name, dtype):
     for k, gw in zip(leaves, wg[1:]):
         err = float((params[k].grad.cpu() - gw).abs().max())
         assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
+
+
+def _fixture(name):
+    from oracle import cases as C
+    case = C.CASES[name]
+    shapes, ref_outs = C.load_fixture(os.path.join(GOLD, f"{name}.npz"))
+    sd = C.case_state_dict(case, shapes) if shapes else {}
+    return C, case, sd, ref_outs, case["inputs"]()
+
+
+def _check(C, got, want, ref, tol, what):
+    got = got.float().cpu().reshape(want.shape)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{what}: max |hip - oracle| = {err} (scale {scale})"
+    assert float(np.abs(C.subsample(got) - ref["sub"]).max()) <= tol * scale, f"{what}: differs from the reference fixture"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trajectory_fixture_through_the_product_module(dtype):
+    """trajectory_c32 (the reference's Trajectory_multi_head on 5 frames, stride 2, two residual blocks, models/trajectory.py:300-490) replayed through
+    vmg_amd.model.Trajectory_multi_head: lock-step sweeps, flow warp, location advection, window attention, residual chain, fusion."""
+    from vmg_amd.model import Trajectory_multi_head
+    C, case, sd, ref, inp = _fixture("trajectory_c32")
+    m = Trajectory_multi_head(32, 2, 2, 4, True, 0.1, (2, 2)).cuda()
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    with torch.no_grad():
+        got = m(inp["x"].cuda().to(dtype), inp["ff"].cuda(), inp["fb"].cuda())
+        want = case["run"]({k: v.clone() for k, v in sd.items()}, inp)[0]
+    _check(C, got, want, ref[0], 2e-4 if dtype == torch.float32 else 4e-2, f"trajectory_c32 ({dtype})")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ltam_fixture_through_the_product_module(dtype):
+    """ltam_wins (LTAM_multi_head.forward_wins incl. the output projection and the anchor add, models/trajectory.py:672-795) through
+    vmg_amd.model.LTAM_multi_head."""
+    from vmg_amd.model import LTAM_multi_head
+    C, case, sd, ref, inp = _fixture("ltam_wins")
+    m = LTAM_multi_head(144, 4, True, (2, 2)).cuda()
+    m.load_state_dict(sd, strict=True)
+    dev = lambda t: t.cuda().to(dtype).contiguous()
+    with torch.no_grad():
+        got = m(dev(inp["q"]), [dev(k) for k in inp["keys"].unbind(1)], dev(inp["anchor"]), [dev(v) for v in inp["vals"].unbind(1)], inp["loc"].cuda())
+        want = case["run"]({k: v.clone() for k, v in sd.items()}, inp)[0]
+    _check(C, got, want, ref[0], 2e-4 if dtype == torch.float32 else 3e-2, f"ltam_wins ({dtype})")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sr_head_fixture_through_the_product_head(dtype):
+    """sr_head (upconv1 / PixelShuffle / lrelu, upconv2 / PixelShuffle / lrelu, HRconv / lrelu, conv_last; models/vmg.py:629-632) through
+    VMG.reconstruct -- the fused PixelShuffle epilogue / the weight-streaming conv + shuffle pass, the 64-channel HR convs."""
+    import types
+    import torch.nn as nn
+    from vmg_amd.model import VMG
+    C, case, sd, ref, inp = _fixture("sr_head")
+    holder = nn.Module()
+    holder.upconv1, holder.upconv2 = nn.Conv2d(144, 576, 3, 1, 1), nn.Conv2d(144, 256, 3, 1, 1)
+    holder.HRconv, holder.conv_last = nn.Conv2d(64, 64, 3, 1, 1), nn.Conv2d(64, 3, 3, 1, 1)
+    holder.load_state_dict(sd, strict=True)
+    holder.cuda()
+    y = inp["y"]
+    N, H, W, _ = y.shape
+    with torch.no_grad():
+        got = VMG.reconstruct(holder, y.cuda().to(dtype), N, H, W)
+        want = case["run"]({k: v.clone() for k, v in sd.items()}, inp)[0]
+    _check(C, got, want, ref[0], 2e-4 if dtype == torch.float32 else 3e-2, f"sr_head ({dtype})")
+
+
+def test_flow_smoothing_fixture_on_the_gpu():
+    """flow_smoothing (reflect pad to a multiple of 4, 4 x 4 mean, nearest x 4, crop; models/function.py:1466-1478) as the product runs
+    it (Mlp_encoder.flow_smoothing, 30 x 26 maps: both paddings active), forward vs the fixture and the gradient vs the oracle's autograd."""
+    from oracle import vmg_oracle as O
+    from vmg_amd.model import Mlp_encoder
+    C, case, sd, ref, inp = _fixture("flow_smoothing")
+    f = inp["flow"]
+    fo = f.clone().requires_grad_(True)
+    want = O.flow_smoothing(fo, 4)
+    go = torch.randn(want.shape, generator=torch.Generator().manual_seed(5))
+    (wg,) = torch.autograd.grad(want, fo, go)
+    fd = f.cuda().requires_grad_(True)
+    got = Mlp_encoder.flow_smoothing(fd, 4)
+    (gg,) = torch.autograd.grad(got, fd, go.cuda())
+    _check(C, got.detach(), want.detach(), ref[0], 1e-5, "flow_smoothing")
+    assert float((gg.cpu() - wg).abs().max()) <= 1e-5 * max(1.0, float(wg.abs().max()))

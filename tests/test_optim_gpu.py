@@ -144,3 +144,145 @@ def test_replay_of_a_captured_sequence_matches_the_graph():
     torch.cuda.synchronize()
     assert torch.equal(got, out)
     hip.lib().vmg_replay_destroy(ctypes.c_void_p(h))
+
+
+def test_flat_adamw_state_dict_survives_the_relayout():
+    """FlatAdamW.state_dict() is keyed per parameter in construction order: a checkpoint written AFTER relayout() (the data-parallel
+    re-layout by gradient-completion order) loads into a fresh optimizer in registration-order layout with every moment on its own
+    parameter, and a checkpoint of the fresh layout loads into a re-laid-out optimizer; mismatching parameter lists are refused."""
+    from vmg_amd.train import FlatAdamW
+
+    def make(seed=1):
+        ps = [torch.nn.Parameter(p.detach().clone().cuda()) for p in _params(seed)]
+        return ps, FlatAdamW([{"params": ps[:2], "lr": 0.0}, {"params": ps[2:]}], lr=1e-3)
+
+    pa, a = make()
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(2):
+        for p in pa:
+            p.grad.copy_((torch.randn(p.shape, generator=gen) * 0.01).cuda())
+        a.step()
+    a.relayout([pa[6], pa[3], pa[5], pa[1], pa[0], pa[2], pa[4]])  # permute inside the groups
+    for p in pa:
+        p.grad.copy_((torch.randn(p.shape, generator=gen) * 0.01).cuda())
+    a.step()
+    sd = a.state_dict()
+    off_a = {id(p): o for p, o in zip(a.params, a.offsets)}
+    pb, b = make()
+    b.load_state_dict(sd)
+    assert b.t == a.t == 3
+    off_b = {id(p): o for p, o in zip(b.params, b.offsets)}
+    assert [off_a[id(p)] for p in pa] != [off_b[id(p)] for p in pb]  # the two layouts really differ
+    for x, y in zip(pa, pb):
+        n = x.numel()
+        assert torch.equal(a.m[off_a[id(x)]:off_a[id(x)] + n], b.m[off_b[id(y)]:off_b[id(y)] + n])
+        assert torch.equal(a.v[off_a[id(x)]:off_a[id(x)] + n], b.v[off_b[id(y)]:off_b[id(y)] + n])
+    # and back: the fresh layout's checkpoint into the re-laid-out optimizer; the next steps agree bit for bit
+    a.load_state_dict(b.state_dict())
+    with torch.no_grad():
+        for x, y in zip(pa, pb):
+            y.copy_(x)
+    for p, q in zip(pa, pb):
+        g = (torch.randn(p.shape, generator=gen) * 0.01).cuda()
+        p.grad.copy_(g)
+        q.grad.copy_(g)
+    a.step()
+    b.step()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x.detach(), y.detach())
+    ps, c = make()
+    bad = dict(sd)
+    bad["numel"] = sd["numel"][:-1]
+    with pytest.raises(ValueError):
+        c.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        c.load_state_dict({"t": 1, "m": a.m, "v": a.v, "groups": sd["groups"]})  # (round 2's positional format)
+
+
+@pytest.mark.parametrize("max_norm", [0.05, 1e6])
+def test_clip_grad_norm_on_the_flat_buffer(max_norm):
+    """vmg_grad_clip_norm against torch.nn.utils.clip_grad_norm_ (what tools/Trainer.py:141-143 calls): total norm, coefficient, clipped
+    gradients; a max_norm above the norm leaves the gradients untouched; two runs give the same bits."""
+    from vmg_amd.train import FlatAdamW
+    ps = [torch.nn.Parameter(p.detach().clone().cuda()) for p in _params(4)]
+    opt = FlatAdamW([{"params": ps[:2], "lr": 0.0}, {"params": ps[2:]}], lr=1e-3)
+    gen = torch.Generator().manual_seed(5)
+    gs = [torch.randn(p.shape, generator=gen) * 0.02 for p in ps]
+    refs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    for r, g in zip(refs, gs):
+        r.grad = g.clone()
+    want_norm = torch.nn.utils.clip_grad_norm_(refs, max_norm, norm_type=2)
+    outs = []
+    for _ in range(2):
+        for p, g in zip(ps, gs):
+            p.grad.copy_(g.cuda())
+        res = opt.clip_grad_norm_(max_norm).clone()
+        outs.append((res, opt.g.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert abs(float(outs[0][0][0]) - float(want_norm)) <= 1e-6 * float(want_norm)
+    for p, r, g in zip(ps, refs, gs):
+        assert float((p.grad.cpu() - r.grad).abs().max()) <= 1e-6 * float(g.abs().max())
+        if max_norm > 1.0:
+            assert torch.equal(p.grad.cpu(), g)
+
+
+def test_train_step_schedule_clip_and_accumulation():
+    """TrainStep with the reference's step pieces (tools/Trainer.py:125-190, 244-272): (a) the learning rates follow LRSchedule after every
+    optimizer step -- SPyNet stays frozen until flow_fix and then moves; (b) grad_clip bounds the gradient norm the optimizer sees; (c) two
+    accumulated micro-steps (loss / 2 each, update on the second) leave the same gradient in the flat buffer as the sum of two separate
+    backward passes halved."""
+    from oracle import cases as C
+    from tests.util import build_product
+    from vmg_amd.train import TrainStep
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    cfg = C.cfg_tiny_few(3, is_train=False)  # (drop-path 0: the passes are repeatable)
+    shapes, _ = C.load_fixture(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(C.CASES["vmg_tiny_few"], shapes)
+    xs = [synthetic_clip(1, 3, 64, 64, seed=70 + i, device="cuda") for i in range(2)]
+    ys = [synthetic_target(x) for x in xs]
+
+    m = build_product(cfg, torch.float32)
+    m.load_state_dict(sd)
+    m.train()
+    ts = TrainStep(m, lr=2e-4, schedule=dict(T_period=[40], eta_min=1e-7, flow_fix=1, pre_lr_ratio=0.125, warmup_iter=-1), grad_clip=1e-3)
+    spy0 = torch.cat([p.detach().reshape(-1).clone() for p in m.spynet.parameters()])
+    seen = []
+    ts.grad_hook = lambda t: seen.append(float(t.opt.g.double().square().sum().sqrt()))
+    lrs = []
+    for it in range(4):
+        ts(xs[it % 2], ys[it % 2])
+        lrs.append([g["lr"] for g in ts.opt.param_groups])
+        spy = torch.cat([p.detach().reshape(-1) for p in m.spynet.parameters()])
+        if it <= 1:  # steps 0 and 1 ran with SPyNet's lr 0 (cur_iter <= flow_fix keeps it frozen for the NEXT step too)
+            assert torch.equal(spy, spy0), it
+    assert not torch.equal(spy, spy0)  # step 3 ran with lr = group 1's lr * 0.125
+    want = C.oracle_lr_update(dict(T_period=[40], restarts=None, weights=None, eta_min=1e-7, base=[0.0, 2e-4], flow_fix=1, pre_lr_ratio=0.125,
+                                   warmup_iter=-1, reduced_iter=None, steps=4))
+    assert lrs == want
+    assert all(n <= 1e-3 * (1 + 1e-5) for n in seen), seen  # the optimizer saw clipped gradients
+    assert float(ts.grad_norm[0]) > 1e-3 and 0 < float(ts.grad_norm[1]) < 1
+
+    # (c) accumulation
+    def fresh():
+        mm = build_product(cfg, torch.float32)
+        mm.load_state_dict(sd)
+        mm.train()
+        return mm, TrainStep(mm, lr=0.0)
+    m1, t1 = fresh()
+    got = {}
+    t1.grad_hook = lambda t: got.update({n: p.grad.clone() for n, p in m1.named_parameters()})
+    t1(xs[0], ys[0], grad_acc=2, update=False)
+    assert t1.iter == 0
+    t1(xs[1], ys[1], grad_acc=2, update=True)
+    assert t1.iter == 1 and float(t1.opt.g.abs().max()) == 0.0
+    single = []
+    for i in range(2):
+        m2, t2 = fresh()
+        g2 = {}
+        t2.grad_hook = lambda t, g2=g2, m2=m2: g2.update({n: p.grad.clone() for n, p in m2.named_parameters()})
+        t2(xs[i], ys[i])
+        single.append(g2)
+    gmax = max(float(v.abs().max()) for v in single[0].values())
+    for n in got:
+        ref = 0.5 * (single[0][n] + single[1][n])
+        assert float((got[n] - ref).abs().max()) <= 2e-3 * max(float(ref.abs().max()), 1e-3 * gmax), n

@@ -33,7 +33,7 @@ struct LtamK {
   // backward
   const char* dout;
   char* dq;            // (n,h,w,c) T
-  void* dk_acc[LT_MAX_T];  // (n,h,w,c) accumulators in the tensors' dtype, zero-initialised
+  void* dk_acc[LT_MAX_T];  // (n,h,w,c) fp32 accumulators, zero-initialised (or holding earlier calls' sums)
   void* dv_acc[LT_MAX_T];
   float* drpe;         // (heads, wq, wq) fp32, accumulated
   int n, h, w, c, t, wh, ww;
@@ -220,33 +220,16 @@ __global__ __launch_bounds__(256) void ltam_fwd_kernel(const LtamK a) {
 // then the normalisation Jacobians are applied and dK/dV rows are scattered (float atomics) to the gather sources.
 // Scatter-add of the tile's 64 gradient rows (fp32 in LDS, [64][C]) to their gather sources.  Lanes run along CHANNELS: every atomic
 // wave-instruction adds 256 contiguous bytes -- the full-rate shape of global atomics here (a lane-per-head-slice scatter strides the lanes
-// by D elements and was ~10x slower).  fp32 tensors: float atomics.  bf16 tensors: PACKED bf16 atomics (global_atomic_pk_add_bf16, two
-// channels per lane) straight into a bf16 accumulator: half the atomic instructions, and neither a zero-fill nor a cast pass over an fp32
-// copy of every key / value frame (a third of the backward's time at 6 key-frames); several rows landing on one source pixel are then
-// summed in bf16, as autograd sums the bf16 gradients of the calls that share a key-frame anyway.
-typedef __attribute__((ext_vector_type(2))) short lt_s16x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 lt_bf16x2;
-template <typename T, int C>
+// by D elements and was ~10x slower).  The accumulators are fp32 for every tensor dtype: a key-frame collects rows from up to six later
+// frames and from several queries each; a bf16 running sum (packed bf16 atomics, round 2) rounded at every add, order-dependently.  The
+// caller rounds the finished sums to bf16 once.
+template <int C>
 __device__ __forceinline__ void scatter_rows(void* acc, long long img, const float* rowbuf, const int* sidx, const int* selfidx, int tid, bool skip) {
-  if constexpr (sizeof(T) == 2) {
-    constexpr int C2 = C / 2;
-    bf16* dst = reinterpret_cast<bf16*>(acc);
-    for (int i = tid; i < LT_PIX * C2; i += 256) {
-      const int pp = i / C2, ch = 2 * (i - pp * C2);
-      const int sp = sidx[pp];
-      if (sp >= 0 && selfidx[pp] >= 0 && !skip) {
-        const lt_bf16x2 v = {(bf16)rowbuf[pp * C + ch], (bf16)rowbuf[pp * C + ch + 1]};
-        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) lt_s16x2*)(dst + (img + sp) * C + ch),
-                                                   __builtin_bit_cast(lt_s16x2, v));
-      }
-    }
-  } else {
-    float* dst = reinterpret_cast<float*>(acc);
-    for (int i = tid; i < LT_PIX * C; i += 256) {
-      const int pp = i / C, ch = i - pp * C;
-      const int sp = sidx[pp];
-      if (sp >= 0 && selfidx[pp] >= 0 && !skip) atomicAdd(dst + (img + sp) * C + ch, rowbuf[i]);
-    }
+  float* dst = reinterpret_cast<float*>(acc);
+  for (int i = tid; i < LT_PIX * C; i += 256) {
+    const int pp = i / C, ch = i - pp * C;
+    const int sp = sidx[pp];
+    if (sp >= 0 && selfidx[pp] >= 0 && !skip) atomicAdd(dst + (img + sp) * C + ch, rowbuf[i]);
   }
 }
 
@@ -420,12 +403,12 @@ __global__ __launch_bounds__(256) void ltam_bwd_kernel(const LtamK a) {
 #pragma unroll
       for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = (dkn[d] - kn[d] * nd) * inv;
       __syncthreads();
-      scatter_rows<T, c>(a.dk_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
+      scatter_rows<c>(a.dk_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
       __syncthreads();
 #pragma unroll
       for (int d = 0; d < D; ++d) rowbuf[p * c + hd * D + d] = dv[d];
       __syncthreads();
-      scatter_rows<T, c>(a.dv_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
+      scatter_rows<c>(a.dv_acc[j], img, rowbuf, sidx, selfidx, tid, LT_ABL(1));
     }
   }
   // query normalisation Jacobian

@@ -40,7 +40,79 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
   }
 }
 
+// ---- clip_grad_norm_ over the flat gradient buffer (tools/Trainer.py:141-143, 166-167: torch.nn.utils.clip_grad_norm_, norm_type 2) ----
+// Two launches, no atomics: per-block sums of squares over fixed contiguous chunks (fixed order inside a block: a strided walk, wave
+// shuffles, the four waves through LDS), then every block of the second launch adds the partials in index order -- in double -- and
+// scales its own chunk by min(1, max_norm / (norm + 1e-6)).  The result is the same bits on every run and for any gradient-arrival order.
+constexpr int CLIP_BLOCKS = 1024;
+
+__device__ __forceinline__ double block_sum_double(double v, double* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ partial) {
+  __shared__ double sm[4];
+  const long long n4 = n >> 2;
+  const long long per = (n4 + CLIP_BLOCKS - 1) / CLIP_BLOCKS;
+  const long long lo = blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+  float acc = 0.f;
+  double total = 0.0;
+  int k = 0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (++k == 64) { total += acc; acc = 0.f; k = 0; }  // (fp32 runs of at most 256 squares, summed in double)
+  }
+  total += acc;
+  if (blockIdx.x == CLIP_BLOCKS - 1)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) total += (double)g[i] * g[i];
+  const double s = block_sum_double(total, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void grad_clip_scale_kernel(float* __restrict__ g, long long n, const double* __restrict__ partial, float max_norm,
+                                                              float* __restrict__ norm_out) {
+  __shared__ double sm[4];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 256) t += partial[i];
+  const double total = block_sum_double(t, sm);
+  const float norm = (float)sqrt(total);
+  float coef = max_norm / (norm + 1e-6f);
+  coef = coef < 1.0f ? coef : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { norm_out[0] = norm; norm_out[1] = coef; }
+  if (coef >= 1.0f) return;
+  const long long n4 = n >> 2;
+  const long long per = (n4 + CLIP_BLOCKS - 1) / CLIP_BLOCKS;
+  const long long lo = blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    float4 v = reinterpret_cast<float4*>(g)[i];
+    v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    reinterpret_cast<float4*>(g)[i] = v;
+  }
+  if (blockIdx.x == CLIP_BLOCKS - 1)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) g[i] *= coef;
+}
+
 }  // namespace
+
+extern "C" int64_t vmg_grad_clip_ws_bytes() { return (int64_t)CLIP_BLOCKS * sizeof(double); }
+
+extern "C" int vmg_grad_clip_norm(float* g, int64_t n, float max_norm, void* workspace, float* norm_out, void* stream) {
+  VMG_CHECK(g && workspace && norm_out && n > 0 && max_norm > 0.f, "grad_clip_norm: bad arguments");
+  VMG_CHECK(((uintptr_t)g % 16 == 0) && ((uintptr_t)workspace % 8 == 0), "grad_clip_norm: the gradient buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, (long long)n, (double*)workspace);
+  VMG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_clip_scale_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, (long long)n, (const double*)workspace, max_norm,
+                     norm_out);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vmg_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2, float eps,
                               void* stream) {

@@ -15,8 +15,10 @@ struct V16 {
 // ------------------------------------------------------------------------------------------------ reduction
 // mode 0: out[g,c] += scale * sum_r (a [+ b + c3])[g,r,c]      mode 1: out[g,c] += scale * sum_r a*b
 // Threads run along 16-byte channel vectors (VN = 8 bf16 / 4 fp32 channels; VN = 2 when C is not a multiple of that),
-// 256/tpr rows per block iteration; the row-parallel partials are combined in LDS and added to the zero-initialised
-// output with one float atomic per channel and block.
+// 256/tpr rows per block iteration; the row-parallel partials are combined in LDS in a fixed order and written to the block's row of a
+// PARTIALS workspace [G][chunks][C]; group_reduce_final_kernel then adds the chunks of a group in index order.  No atomics: the pooled
+// sums -- and with them the whole forward pass -- are the same bits on every run (round 2 added the block partials with float atomics,
+// in arrival order).  The final kernel takes the launch slot of the zero-fill the atomic version needed.
 template <typename T, int VN>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c3,
                                                            float* __restrict__ out, int G, long long R, int C, int mode, float scale,
@@ -77,8 +79,20 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__
     const int cp2 = c / VN, e = c - cp2 * VN;
     float t = 0.f;
     for (int k = 0; k < rpb; ++k) t += red[e * 256 + k * tpr + cp2];
-    atomicAdd(out + (long long)g * C + c, t * scale);
+    out[((long long)g * chunks + ck) * C + c] = t;
   }
+}
+
+// out[g, i] = scale * sum over the group's chunks, in chunk order, of partial[g][chunk][i]; `width` = C (or 3C for group_reduce3).
+__global__ __launch_bounds__(256) void group_reduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int G, int chunks, int width,
+                                                                 float scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * width) return;
+  const int g = i / width, c = i - g * width;
+  const float* p = partial + (long long)g * chunks * width + c;
+  float t = 0.f;
+  for (int k = 0; k < chunks; ++k) t += p[(long long)k * width];
+  out[i] = t * scale;
 }
 
 // out (G, C, 3) += scale * sum_r a * {b0, b1, b2}: the three branch sums of the MorphFC re-weighting backward (d softmax-weights) from ONE
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void group_reduce3_kernel(const T* __restrict_
     const int cp2 = c / VN, e = c - cp2 * VN;
     float t = 0.f;
     for (int j = 0; j < rpb; ++j) t += red[(k * VN + e) * 256 + j * tpr + cp2];
-    atomicAdd(out + ((long long)g * C + c) * 3 + k, t * scale);
+    out[(((long long)g * chunks + ck) * C + c) * 3 + k] = t;
   }
 }
 
@@ -446,54 +460,65 @@ extern "C" int vmg_maxpool_bwd(int dtype, const void* dy, const unsigned char* i
   return 0;
 }
 
-extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode,
-                                float scale, void* stream) {
-  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "group_reduce: bad dtype");
-  VMG_CHECK(a && out && G > 0 && R > 0 && C > 0 && (C & 1) == 0 && C <= 512, "group_reduce: bad arguments (C even, <= 512)");
-  VMG_CHECK(mode == 0 || (mode == 1 && b), "group_reduce: mode 1 needs b");
+extern "C" int64_t vmg_group_reduce_ws_bytes() { return (int64_t)1024 * 3 * 512 * sizeof(float); }  // [<= 1024 blocks][<= 3 * 512 sums]
+
+static int gr_chunks(int G, int64_t R) {
   int chunks = (int)(1024 / G);
 #ifdef VMG_DIAG
   { const char* e = getenv("VMG_GR_BLOCKS"); if (e && atoi(e) > 0) chunks = atoi(e) / G; }  // (tools/bench_group_reduce.py)
 #endif
   if (chunks < 1) chunks = 1;
   if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
+  return chunks;
+}
+
+extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const void* c3, float* out, int G, int64_t R, int C, int mode,
+                                float scale, float* ws, int64_t ws_bytes, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "group_reduce: bad dtype");
+  VMG_CHECK(a && out && ws && G > 0 && R > 0 && C > 0 && (C & 1) == 0 && C <= 512, "group_reduce: bad arguments (C even, <= 512)");
+  VMG_CHECK(mode == 0 || (mode == 1 && b), "group_reduce: mode 1 needs b");
+  const int chunks = gr_chunks(G, R);
+  VMG_CHECK((int64_t)G * chunks * C * (int64_t)sizeof(float) <= ws_bytes, "group_reduce: workspace too small (vmg_group_reduce_ws_bytes)");
   hipStream_t st = (hipStream_t)stream;
   const bool al16 = ((uintptr_t)a % 16 == 0) && (!b || (uintptr_t)b % 16 == 0) && (!c3 || (uintptr_t)c3 % 16 == 0);
   if (dtype == VMG_BF16) {
     if (C % 8 == 0 && al16)
-      hipLaunchKernelGGL((group_reduce_kernel<bf16, 8>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out,
+      hipLaunchKernelGGL((group_reduce_kernel<bf16, 8>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, ws,
                          G, (long long)R, C, mode, scale, chunks);
     else
-      hipLaunchKernelGGL((group_reduce_kernel<bf16, 2>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, out,
+      hipLaunchKernelGGL((group_reduce_kernel<bf16, 2>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c3, ws,
                          G, (long long)R, C, mode, scale, chunks);
   } else {
     if (C % 4 == 0 && al16)
       hipLaunchKernelGGL((group_reduce_kernel<float, 4>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3,
-                         out, G, (long long)R, C, mode, scale, chunks);
+                         ws, G, (long long)R, C, mode, scale, chunks);
     else
       hipLaunchKernelGGL((group_reduce_kernel<float, 2>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c3,
-                         out, G, (long long)R, C, mode, scale, chunks);
+                         ws, G, (long long)R, C, mode, scale, chunks);
   }
+  VMG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(cdiv(G * C, 256)), dim3(256), 0, st, (const float*)ws, out, G, chunks, C, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmg_group_reduce3(int dtype, const void* a, const void* b0, const void* b1, const void* b2, float* out, int G, int64_t R, int C,
-                                 float scale, void* stream) {
+                                 float scale, float* ws, int64_t ws_bytes, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "group_reduce3: bad dtype");
   const int vn = dtype == VMG_BF16 ? 8 : 4;
-  VMG_CHECK(a && b0 && b1 && b2 && out && G > 0 && R > 0 && C > 0 && C % vn == 0 && C / vn <= 256, "group_reduce3: bad arguments (C a multiple of %d)", vn);
+  VMG_CHECK(a && b0 && b1 && b2 && out && ws && G > 0 && R > 0 && C > 0 && C % vn == 0 && C / vn <= 256 && C <= 512, "group_reduce3: bad arguments (C a multiple of %d, <= 512)", vn);
   VMG_CHECK((((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2) % 16) == 0, "group_reduce3: pointers must be 16-byte aligned");
-  int chunks = (int)(1024 / G);
-  if (chunks < 1) chunks = 1;
-  if (chunks > R / 64) chunks = (int)(R / 64 > 0 ? R / 64 : 1);
+  const int chunks = gr_chunks(G, R);
+  VMG_CHECK((int64_t)G * chunks * C * 3 * (int64_t)sizeof(float) <= ws_bytes, "group_reduce3: workspace too small (vmg_group_reduce_ws_bytes)");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VMG_BF16)
     hipLaunchKernelGGL((group_reduce3_kernel<bf16, 8>), dim3(G * chunks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b0, (const bf16*)b1,
-                       (const bf16*)b2, out, G, (long long)R, C, scale, chunks);
+                       (const bf16*)b2, ws, G, (long long)R, C, scale, chunks);
   else
     hipLaunchKernelGGL((group_reduce3_kernel<float, 4>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b0, (const float*)b1,
-                       (const float*)b2, out, G, (long long)R, C, scale, chunks);
+                       (const float*)b2, ws, G, (long long)R, C, scale, chunks);
+  VMG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(cdiv(G * C * 3, 256)), dim3(256), 0, st, (const float*)ws, out, G, chunks, 3 * C, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -74,18 +74,16 @@ __global__ __launch_bounds__(256) void warp_bilinear_fwd_kernel(const T* __restr
   }
 }
 
-// backward: dx_acc (zero-initialised, the tensors' dtype) += scatter of dy; dflow = channel reductions.
+// backward: dx_acc (zero-initialised, ALWAYS fp32) += scatter of dy; dflow = channel reductions.
 // One WAVE per output pixel, lanes along channels: every atomic wave-instruction adds 256 contiguous bytes, the full-rate shape of
 // global atomics on this chip (a lane-per-vector mapping strides the lanes by 32 B and ran 10x slower), and the flow gradient is a
-// wave reduction written without atomics.  fp32: float atomics, one channel per lane.  bf16: PACKED bf16 atomics
-// (global_atomic_pk_add_bf16), two channels per lane, straight into a bf16 accumulator -- a third fewer atomic instructions at 144
-// channels and neither a zero-fill nor a cast pass over an fp32 copy of the frame; the up to four (typically) contributions a source
-// pixel receives are summed in bf16.
-typedef __attribute__((ext_vector_type(2))) short wp_s16x2;
+// wave reduction written without atomics.  The accumulator is fp32 for bf16 tensors too: with border padding many output pixels clamp
+// onto the same source pixels, and a bf16 running sum (global_atomic_pk_add_bf16, round 2) rounds to 8 bits at every add -- order-dependent,
+// small addends swamped, 52-75 % of the elements different between two identical launches.  fp32 sums are rounded to bf16 ONCE by the caller.
 typedef __attribute__((ext_vector_type(2))) __bf16 wp_bf16x2;
 template <typename T>
 __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restrict__ x, const float* __restrict__ flow,
-                                                                const T* __restrict__ dy, T* __restrict__ dx_acc,
+                                                                const T* __restrict__ dy, float* __restrict__ dx_acc,
                                                                 float* __restrict__ dflow, int N, int H, int W, int C) {
   const int lane = threadIdx.x & 63;
   const long long npix = (long long)N * H * W;
@@ -109,18 +107,27 @@ __global__ __launch_bounds__(256) void warp_bilinear_bwd_kernel(const T* __restr
     const long long osw = ib + ((long long)y1 * W + x0) * C, ose = ib + ((long long)y1 * W + x1) * C;
     float gix = 0.f, giy = 0.f;
     if constexpr (sizeof(T) == 2) {
-      typedef __attribute__((address_space(1))) wp_s16x2* gptr;
-      for (int c = 2 * lane; c < C; c += 128) {  // (C is even: the host checks)
-        const wp_bf16x2 gp = *reinterpret_cast<const wp_bf16x2*>(dy + pix * C + c);
-        const float g0 = (float)gp[0], g1 = (float)gp[1];
+      // two passes of one channel per lane over each 128-channel block: lanes 0..63 add 256 contiguous bytes per atomic instruction
+      for (int cb = 0; cb < C; cb += 128) {
+        const int cp = cb + 2 * lane;          // this lane's channel PAIR for the loads (4-byte loads of dy and the four corners)
+        const bool in = cp < C;                // (C is even: the host checks)
+        const long long own = pix * C;
+        const int cl = in ? cp : 0;
+        const wp_bf16x2 gp = *reinterpret_cast<const wp_bf16x2*>(dy + own + cl);
         // the four corner reads are unconditional and issued together (a corner outside the image re-reads this pixel's own x and is dropped):
         // loads behind a branch are waited for one by one
-        const long long own = pix * C;
-        const wp_bf16x2 xnw = *reinterpret_cast<const wp_bf16x2*>(x + (vnw ? onw : own) + c), xne = *reinterpret_cast<const wp_bf16x2*>(x + (vne ? one : own) + c);
-        const wp_bf16x2 xsw = *reinterpret_cast<const wp_bf16x2*>(x + (vsw ? osw : own) + c), xse = *reinterpret_cast<const wp_bf16x2*>(x + (vse ? ose : own) + c);
+        const wp_bf16x2 xnw = *reinterpret_cast<const wp_bf16x2*>(x + (vnw ? onw : own) + cl), xne = *reinterpret_cast<const wp_bf16x2*>(x + (vne ? one : own) + cl);
+        const wp_bf16x2 xsw = *reinterpret_cast<const wp_bf16x2*>(x + (vsw ? osw : own) + cl), xse = *reinterpret_cast<const wp_bf16x2*>(x + (vse ? ose : own) + cl);
+        const float g0 = in ? (float)gp[0] : 0.f, g1 = in ? (float)gp[1] : 0.f;
+        // the loads hold channel PAIRS per lane; the atomics want one channel per lane, lanes along channels (256 contiguous bytes per
+        // instruction): lane l adds channels cb + l and cb + 64 + l, fetched from the lanes that loaded them
+        const int sl = lane >> 1;
+        const float a0 = __shfl(g0, sl, 64), a1 = __shfl(g1, sl, 64), b0 = __shfl(g0, 32 + sl, 64), b1 = __shfl(g1, 32 + sl, 64);
+        const float glo = (lane & 1) ? a1 : a0, ghi = (lane & 1) ? b1 : b0;
+        const int clo = cb + lane, chi = cb + 64 + lane;
         auto corner = [&](long long o, float wgt, float sx, float sy, wp_bf16x2 xp) __attribute__((always_inline)) {
-          const wp_bf16x2 a = {(__bf16)(g0 * wgt), (__bf16)(g1 * wgt)};
-          __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr)(dx_acc + o + c), __builtin_bit_cast(wp_s16x2, a));
+          if (clo < C) atomicAdd(dx_acc + o + clo, glo * wgt);
+          if (chi < C) atomicAdd(dx_acc + o + chi, ghi * wgt);
           const float xv = (float)xp[0] * g0 + (float)xp[1] * g1;
           gix += xv * sx;
           giy += xv * sy;
@@ -200,7 +207,7 @@ extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VMG_BF16) {
     VMG_CHECK(C % 2 == 0 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx_acc) % 4 == 0, "warp_bwd: bf16 needs an even channel count and 4-byte aligned tensors");
-    hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, (bf16*)dx_acc, dflow, N, H, W, C);
+    hipLaunchKernelGGL(warp_bilinear_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, flow, (const bf16*)dy, (float*)dx_acc, dflow, N, H, W, C);
   } else {
     hipLaunchKernelGGL(warp_bilinear_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, flow, (const float*)dy, (float*)dx_acc, dflow, N, H, W, C);
   }

@@ -235,14 +235,18 @@ class _DeferredWgrad:
         self.ready = []     # [weight, bias, entries] whose last use has been seen, not batchable: launched by drain()
         self.waiting = {}   # multi-launch signature -> complete parameters waiting for company (launched at eight, or by drain())
         self.hold = 0       # > 0: a node that completes many parameters at once (a residual chain) is collecting them
+        self.extra = {}     # (generation, id(param)) -> outstanding contributions of OTHER nodes to a managed bias (note_extra)
+        self.held = {}      # id(param) -> param whose weight-gradient launch is done while such a contribution is still outstanding
+        self.bw_gen = 0     # generation of the backward pass that is running (taken from the recorded entries)
 
     def begin_forward(self):
         """New top-level forward pass: a fresh generation; counts of passes older than KEEP_GENERATIONS are dropped."""
         self.gen += 1
-        if self.uses:
+        if self.uses or self.extra:
             lo = self.gen - self.KEEP_GENERATIONS
-            for key in [k for k in self.uses if k[0] < lo]:
-                del self.uses[key]
+            for d in (self.uses, self.extra):
+                for key in [k for k in d if k[0] < lo]:
+                    del d[key]
 
     def note_use(self, weight, bias=None) -> int:
         key = (self.gen, id(weight))
@@ -264,6 +268,38 @@ class _DeferredWgrad:
             self.managed.add(id(p))
         return self.gen
 
+    # -- a bias that a Linear / conv manages (its gradient is written by the deferred weight-gradient launch) may ALSO receive gradient from
+    #    another node -- the 3-D window attention's q / kv biases, through the zero-padded positions (models/swin_3d.py: the padding is added
+    #    before the Linears, so a padded token's q is the bias).  That node adds straight into .grad and the bias counts as complete only
+    #    when BOTH have written: reporting it at the weight-gradient launch alone let the gradient reducer start the bucket's all-reduce
+    #    while the attention backward's add was still to come (replicas diverge).
+    def note_extra(self, *params) -> int:
+        for p in params:
+            key = (self.gen, id(p))
+            self.extra[key] = self.extra.get(key, 0) + 1
+            self.managed.add(id(p))
+        return self.gen
+
+    def extra_written(self, gen: int, *params):
+        for p in params:
+            key = (gen, id(p))
+            left = self.extra.get(key, 1) - 1
+            if left > 0:
+                self.extra[key] = left
+                continue
+            self.extra.pop(key, None)
+            if self.held.pop(id(p), None) is not None:
+                for cb in self.callbacks:
+                    cb(p)
+
+    def _complete(self, p):
+        """The deferred launch that writes p's gradient has been issued: report p, unless another node still owes it a contribution."""
+        if self.extra and self.extra.get((self.bw_gen, id(p)), 0) > 0:
+            self.held[id(p)] = p
+            return
+        for cb in self.callbacks:
+            cb(p)
+
     @staticmethod
     def grad_of(p: torch.Tensor) -> torch.Tensor:
         if p.grad is None:
@@ -284,6 +320,7 @@ class _DeferredWgrad:
     def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0):
         ent = self.pending.setdefault(id(weight), [weight, bias, []])
         ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale)))
+        self.bw_gen = gen
         if not self._queued:  # whatever is still pending when this backward() call ends is completed then
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             self._queued = True
@@ -301,6 +338,11 @@ class _DeferredWgrad:
             self.flush(self.pending[key][0])
         self.hold = 0
         self.drain()
+        if self.held:  # (a contribution that never came -- its node was not part of this backward: the gradient is what it is)
+            held, self.held = self.held, {}
+            for p in held.values():
+                for cb in self.callbacks:
+                    cb(p)
 
     def flush(self, weight):
         ent = self.pending.pop(id(weight), None)
@@ -356,8 +398,8 @@ class _DeferredWgrad:
         for weight, bias, _ in ents:
             for cb in self.callbacks:
                 cb(weight)
-                if bias is not None and bias.requires_grad:
-                    cb(bias)
+            if bias is not None and bias.requires_grad:
+                self._complete(bias)
 
     def drain(self):
         """Launch everything that is complete: parameters of one shape share launches (eight per launch).  Between drains (a residual
@@ -1165,12 +1207,14 @@ def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
 
 class _GradBank:
     """Gradient accumulator of ONE key / value frame over all the trajectory-attention calls that attend to it (a key-frame of a 7-frame clip
-    is attended by up to 6 later frames): their backward kernels scatter into the same buffer with atomics, instead of each call zero-filling
-    buffers of its own that autograd then sums pairwise."""
-    __slots__ = ("buf",)
+    is attended by up to 6 later frames): their backward kernels scatter into the same FP32 buffer with float atomics, instead of each call
+    zero-filling buffers of its own that autograd then sums pairwise; the sum is rounded to the frame's dtype once, when autograd reaches the
+    frame (_Banked.backward)."""
+    __slots__ = ("buf", "dtype")
 
-    def __init__(self):
+    def __init__(self, dtype):
         self.buf = None
+        self.dtype = dtype
 
 
 class _Banked(_Fn):
@@ -1187,14 +1231,16 @@ class _Banked(_Fn):
         buf, ctx.bank.buf = ctx.bank.buf, None
         if buf is None:
             return g, None
-        return (buf if g is None else buf.add_(g)), None
+        if g is not None:
+            buf.add_(g)  # (fp32 += the gradient of the frame's other uses)
+        return buf.to(ctx.bank.dtype), None  # ONE rounding of the finished sum
 
 
 def grad_bank(x: torch.Tensor) -> torch.Tensor:
     """x as a key / value frame of later ltam_attention calls: the same values; the calls' gradients w.r.t. it are summed in one accumulator."""
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x
-    bank = _GradBank()
+    bank = _GradBank(x.dtype)
     y = _Banked.apply(x, bank)
     y._vmg_bank = bank
     return y
@@ -1229,11 +1275,12 @@ class _LTAM(_Fn):
                 into.append(None)
                 continue
             if b.buf is None:
-                b.buf = torch.zeros_like(q)
+                b.buf = torch.zeros_like(q, dtype=torch.float32)
             into.append(b.buf)
         dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale, dk_into=into[:t], dv_into=into[t:])
-        gkv = [None if into[i] is not None else g for i, g in enumerate(dk + dv)]  # (banked frames: their _Banked node hands the sum on)
-        return (dq, None, drpe, None, None, *gkv)  # (already in q's dtype)
+        # banked frames: their _Banked node hands the sum on; the others: fp32 sums rounded to the tensors' dtype here, once
+        gkv = [None if into[i] is not None else (g if g.dtype == q.dtype else g.to(q.dtype)) for i, g in enumerate(dk + dv)]
+        return (dq, None, drpe, None, None, *gkv)
 
 
 def ltam_attention(q, keys, vals, loc, rpe, decay_v, heads: int, wh: int, ww: int, scale: float):
@@ -1255,12 +1302,22 @@ class _Win3dAttention(_Fn):
         out, lse = K.win3d_attn_forward(q, kv, bq, bkv, tab, heads, wt, shift)
         ctx.cfg = (heads, wt, shift)
         ctx.save_for_backward(q, kv, bq, bkv, tab, out, lse)
+        # the q / kv biases belong to Linears whose deferred weight gradient reports them complete: in mode 'deferred' this node adds its share
+        # (padded positions) straight into .grad and is counted as an outstanding contribution (functional._DeferredWgrad.note_extra)
+        ctx.direct = bq is not None and bkv is not None and DEFERRED.direct(bq, bkv)
+        if ctx.direct:
+            ctx.params, ctx.gen = (bq, bkv), DEFERRED.note_extra(bq, bkv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, kv, bq, bkv, tab, out, lse = ctx.saved_tensors
         heads, wt, shift = ctx.cfg
+        if ctx.direct:
+            into = tuple(DEFERRED.grad_of(p) for p in ctx.params)
+            dq, dkv, dtable, _, _ = K.win3d_attn_backward(q, kv, bq, bkv, tab, out, lse, dout, heads, wt, shift, into=into)
+            DEFERRED.extra_written(ctx.gen, *ctx.params)
+            return dq, dkv, None, None, dtable, None, None, None
         dq, dkv, dtable, dbq, dbkv = K.win3d_attn_backward(q, kv, bq, bkv, tab, out, lse, dout, heads, wt, shift)
         return dq, dkv, dbq, dbkv, dtable, None, None, None
 

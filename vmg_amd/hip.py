@@ -89,7 +89,8 @@ SIGNATURES = {
     "vmg_pack_entry": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_int]),
     "vmg_pack_run": (c_int, [c_void_p, c_int, c_int, c_void_p]),
-    "vmg_group_reduce3": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, ctypes.c_float, c_void_p]),
+    "vmg_group_reduce3": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, ctypes.c_float, c_void_p, c_int64, c_void_p]),
+    "vmg_group_reduce_ws_bytes": (c_int64, []),
     "vmg_se_mlp_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "vmg_se_mlp_bwd": (c_int, [c_void_p] * 12 + [c_int] * 6 + [ctypes.c_float, c_int, c_void_p]),
     "vmg_maxpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -114,6 +115,8 @@ SIGNATURES = {
     "vmg_charbonnier_edge_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "vmg_charbonnier_edge_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "vmg_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_void_p]),
+    "vmg_grad_clip_ws_bytes": (c_int64, []),
+    "vmg_grad_clip_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vmg_tile_accumulate": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p]),
     "vmg_tile_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -126,7 +129,7 @@ SIGNATURES = {
     "vmg_conv_wgrad_ws_bytes": (c_int64, []),
     "vmg_conv_wgrad_batched_ws": (c_int, [c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int64, c_int,
                                           c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
-    "vmg_group_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "vmg_group_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]),
     "vmg_tab_elementwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_int64, c_int, c_void_p]),
     "vmg_prof_begin": (c_int, [c_void_p, c_int, c_int, c_int]),

@@ -462,13 +462,20 @@ def win3d_attn_forward(q, kv, bq, bkv, table, heads: int, wt: int, shift):
     return out, lse
 
 
-def win3d_attn_backward(q, kv, bq, bkv, table, out, lse, dout, heads: int, wt: int, shift):
+def win3d_attn_backward(q, kv, bq, bkv, table, out, lse, dout, heads: int, wt: int, shift, into=None):
+    """into = (dbq, dbkv): existing contiguous fp32 buffers (the biases' .grad) the kernel ADDS its bias gradients to, instead of fresh zeros."""
     B, D, H, W, C, nwin = _win3d_geom(q, kv, table, heads, wt)
     dout = dout.contiguous()
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     dtable = torch.zeros_like(table)
-    dbq = torch.zeros(C, dtype=torch.float32, device=q.device) if bq is not None else None
-    dbkv = torch.zeros(2 * C, dtype=torch.float32, device=q.device) if bkv is not None else None
+    if into is not None:
+        dbq, dbkv = into
+        hip.require_cuda(dbq, dbkv)
+        if dbq.dtype != torch.float32 or dbkv.dtype != torch.float32 or dbq.numel() != C or dbkv.numel() != 2 * C or not dbq.is_contiguous() or not dbkv.is_contiguous():
+            raise HipError("win3d_attn_backward: bias gradient buffers must be contiguous fp32 of C and 2C elements")
+    else:
+        dbq = torch.zeros(C, dtype=torch.float32, device=q.device) if bq is not None else None
+        dbkv = torch.zeros(2 * C, dtype=torch.float32, device=q.device) if bkv is not None else None
     pz = lambda t: t.data_ptr() if t is not None else None
     hip.check(hip.lib().vmg_win3d_attn_bwd(hip.dtype_code(q.dtype), q.data_ptr(), kv.data_ptr(), pz(bq), pz(bkv), table.data_ptr(), out.data_ptr(), lse.data_ptr(),
                                            dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dtable.data_ptr(), pz(dbq), pz(dbkv), B, D, H, W, C, heads, wt,
@@ -706,7 +713,7 @@ def warp_bilinear_forward(x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
 def warp_bilinear_backward(x: torch.Tensor, flow: torch.Tensor, dy: torch.Tensor):
     n, h, w, c = x.shape
     dy = dy.contiguous()
-    dx_acc = torch.zeros((n, h, w, c), dtype=x.dtype, device=x.device)  # (bf16: packed bf16 atomics, no fp32 copy)
+    dx_acc = torch.zeros((n, h, w, c), dtype=torch.float32, device=x.device)  # fp32 sums for bf16 tensors too: rounded once by the caller
     dflow = torch.empty((n, h, w, 2), dtype=torch.float32, device=x.device)  # every element is written
     hip.check(hip.lib().vmg_warp_bilinear_bwd(hip.dtype_code(x.dtype), x.data_ptr(), flow.data_ptr(), dy.data_ptr(), dx_acc.data_ptr(),
                                               dflow.data_ptr(), n, h, w, c, hip.stream_ptr()), "vmg_warp_bilinear_bwd")
@@ -746,8 +753,9 @@ def ltam_forward(q, keys, vals, loc, rpe, decay, heads, wh, ww, scale):
 
 
 def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale, dk_into=None, dv_into=None):
-    """dq, dk[j], dv[j], drpe.  dk_into / dv_into: per key-frame an existing accumulator of q's shape and dtype to scatter into (the gradient of a
-    frame that several calls attend to is summed by the kernel's atomics, see functional.grad_bank), or None for a fresh zeroed one."""
+    """dq, dk[j], dv[j], drpe.  dk / dv are FP32 sums (q's shape) for every tensor dtype: the caller rounds them once.  dk_into / dv_into: per
+    key-frame an existing fp32 accumulator to scatter into (the gradient of a frame that several calls attend to is summed by the kernel's
+    atomics, see functional.grad_bank), or None for a fresh zeroed one."""
     n, h, w, c = q.shape
     t = len(keys)
     dout = dout.contiguous()
@@ -755,11 +763,11 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
     dk = list(dk_into) if dk_into is not None else [None] * t
     dv = list(dv_into) if dv_into is not None else [None] * t
     for a in dk + dv:
-        if a is not None and (a.shape != q.shape or a.dtype != q.dtype or not a.is_contiguous()):
-            raise HipError("ltam_backward: accumulators must be contiguous tensors of q's shape and dtype")
+        if a is not None and (a.shape != q.shape or a.dtype != torch.float32 or not a.is_contiguous()):
+            raise HipError("ltam_backward: accumulators must be contiguous fp32 tensors of q's shape")
     fresh = [i for i, a in enumerate(dk + dv) if a is None]
-    if fresh:  # ONE zero-fill for all new accumulators (bf16 tensors: packed bf16 atomics -- no fp32 copy, no cast pass)
-        acc = torch.zeros((len(fresh), n, h, w, c), dtype=q.dtype, device=q.device)
+    if fresh:  # ONE zero-fill for all new accumulators
+        acc = torch.zeros((len(fresh), n, h, w, c), dtype=torch.float32, device=q.device)
         for slot, i in enumerate(fresh):
             if i < t:
                 dk[i] = acc[slot]
@@ -783,11 +791,25 @@ def group_reduce(a: torch.Tensor, G: int, b: Optional[torch.Tensor] = None, c3: 
     rows = a.numel() // C
     if rows % G or not a.is_contiguous() or any(t is not None and (t.shape != a.shape or t.dtype != a.dtype or not t.is_contiguous()) for t in (b, c3)):
         raise HipError("group_reduce: contiguous tensors of one shape / dtype covering G groups expected")
-    out = torch.zeros((G, C), dtype=torch.float32, device=a.device)
+    out = torch.empty((G, C), dtype=torch.float32, device=a.device)
+    ws = _group_reduce_workspace(a.device)
     hip.check(hip.lib().vmg_group_reduce(hip.dtype_code(a.dtype), a.data_ptr(), b.data_ptr() if b is not None else None,
                                          c3.data_ptr() if c3 is not None else None, out.data_ptr(), G, rows // G, C, mode, scale,
-                                         hip.stream_ptr()), "vmg_group_reduce")
+                                         ws.data_ptr(), ws.numel(), hip.stream_ptr()), "vmg_group_reduce")
     return out
+
+
+_GR_WS = {}
+
+
+def _group_reduce_workspace(device) -> torch.Tensor:
+    """Block-partials workspace of the pooled sums: allocated once per device, reused (the calls are stream-ordered: a call's second launch
+    has read the partials before the next call's first launch writes them)."""
+    key = str(device)
+    ws = _GR_WS.get(key)
+    if ws is None:
+        ws = _GR_WS[key] = torch.empty(int(hip.lib().vmg_group_reduce_ws_bytes()), dtype=torch.uint8, device=device)
+    return ws
 
 
 def group_reduce3(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, G: int, scale: float = 1.0) -> torch.Tensor:
@@ -797,9 +819,10 @@ def group_reduce3(a: torch.Tensor, b0: torch.Tensor, b1: torch.Tensor, b2: torch
     rows = a.numel() // C
     if rows % G or any(t.shape != a.shape or t.dtype != a.dtype or not t.is_contiguous() for t in (a, b0, b1, b2)):
         raise HipError("group_reduce3: contiguous tensors of one shape / dtype covering G groups expected")
-    out = torch.zeros((G, C, 3), dtype=torch.float32, device=a.device)
+    out = torch.empty((G, C, 3), dtype=torch.float32, device=a.device)
+    ws = _group_reduce_workspace(a.device)
     hip.check(hip.lib().vmg_group_reduce3(hip.dtype_code(a.dtype), a.data_ptr(), b0.data_ptr(), b1.data_ptr(), b2.data_ptr(), out.data_ptr(), G,
-                                          rows // G, C, scale, hip.stream_ptr()), "vmg_group_reduce3")
+                                          rows // G, C, scale, ws.data_ptr(), ws.numel(), hip.stream_ptr()), "vmg_group_reduce3")
     return out
 
 

@@ -727,6 +727,14 @@ class VMG(nn.Module):
         x3 = self.decoder_layers[0](self.upsample[0](x2), ff[0], fb[0])
         return x3 + x1
 
+    def reconstruct(self, y, N, H, W):
+        """The 4x head on channels-last features (N,H,W,C) -> (N,4H,4W,3): upconv1 / PixelShuffle / lrelu, upconv2 / PixelShuffle / lrelu,
+        HRconv / lrelu, conv_last (models/vmg.py:629-632)."""
+        o = conv(self.upconv1, [y], N, H, W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
+        o = conv(self.upconv2, [o], N, 2 * H, 2 * W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
+        o = conv(self.HRconv, [o], N, 4 * H, 4 * W, act=ACT_LRELU, slope=0.1)
+        return conv(self.conv_last, [o], N, 4 * H, 4 * W)
+
     def forward(self, x, flow_pretrained=None, config_amp=None):
         B, D, C, H, W = x.size()
         assert H >= 64 and W >= 64, "The height and width must larger than 64."
@@ -780,9 +788,6 @@ class VMG(nn.Module):
         y = y.reshape(N, Hp, Wp, -1)
         if (Hp, Wp) != (H, W):
             y = y[:, :H, :W].contiguous()
-        o = conv(self.upconv1, [y], N, H, W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
-        o = conv(self.upconv2, [o], N, 2 * H, 2 * W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
-        o = conv(self.HRconv, [o], N, 4 * H, 4 * W, act=ACT_LRELU, slope=0.1)
-        o = conv(self.conv_last, [o], N, 4 * H, 4 * W)
+        o = self.reconstruct(y, N, H, W)
         out = o.float().permute(0, 3, 1, 2) + up
         return out.reshape(B, self.num_out_frames, -1, 4 * H, 4 * W).to(in_dtype)

@@ -115,6 +115,84 @@ def cosine_restart_lr(step: int, base_lr: float, T_period: List[int], restarts: 
     return eta_min + 0.5 * (peak - eta_min) * (1 + math.cos(math.pi * (step - start) / T))
 
 
+class LRSchedule:
+    """The per-step learning-rate update of the reference's trainer (tools/Trainer.py:244-272) over an optimizer's parameter groups
+    (group 0 = SPyNet, group 1 = everything else, further groups e.g. the weight-decay group):
+
+      1. the cosine-restart scheduler's RECURSION (utils/lr_scheduler.py:17-33) -- each step scales the group's CURRENT lr, so whatever the
+         steps below wrote into a group is what the next step continues from (the closed form `cosine_restart_lr` holds only while
+         nothing else touches the groups);
+      2. `reduced_iter` (the reference's recover_flag): from that iteration on group 1 trains at half the scheduled rate -- the scheduled
+         value is put back before the scheduler step and halved again after it;
+      3. `pre_training`: SPyNet keeps its initial lr (0) while cur_iter <= flow_fix, then follows group 1 at `pre_lr_ratio`;
+      4. warm-up: for cur_iter < warmup_iter every group's lr is initial_lr * cur_iter / warmup_iter.
+
+    step(cur_iter) is called once per optimizer step, after it, like Trainer.train_one_sample does."""
+
+    def __init__(self, groups, T_period, restarts=None, weights=None, eta_min: float = 0.0, warmup_iter: int = -1, pre_training: bool = True,
+                 flow_fix: Optional[int] = None, pre_lr_ratio: float = 1.0, reduced_iter: Optional[int] = None):
+        self.groups = groups
+        self.T_period = list(T_period)
+        self.restarts = list(restarts) if restarts else [0]
+        self.weights = list(weights) if weights else [1]
+        if len(self.restarts) != len(self.weights):
+            raise ValueError("restarts and their weights do not match.")
+        self.eta_min, self.warmup_iter = float(eta_min), int(warmup_iter)
+        self.pre_training, self.flow_fix, self.pre_lr_ratio = bool(pre_training), flow_fix, float(pre_lr_ratio)
+        self.reduced_iter = reduced_iter
+        self.recover = False if reduced_iter is not None else None
+        self.past_lr = None
+        self.T_max, self.last_restart, self.epoch = self.T_period[0], 0, 0
+        for g in groups:
+            g.setdefault("initial_lr", g["lr"])
+            g["lr"] = g["initial_lr"]  # (the scheduler's construction step)
+        if pre_training and (flow_fix is None or len(groups) < 2):
+            raise ValueError("pre_training needs flow_fix and the SPyNet group in front of the others")
+
+    def _scheduler_step(self):
+        self.epoch += 1
+        e = self.epoch
+        if e in self.restarts:
+            i = self.restarts.index(e)
+            self.last_restart, self.T_max = e, self.T_period[i + 1]
+            for g in self.groups:
+                g["lr"] = g["initial_lr"] * self.weights[i]
+            return
+        T, k = self.T_max, e - self.last_restart
+        if (k - 1 - T) % (2 * T) == 0:
+            for g in self.groups:
+                g["lr"] = g["lr"] + (g["initial_lr"] - self.eta_min) * (1 - math.cos(math.pi / T)) / 2
+            return
+        f = (1 + math.cos(math.pi * k / T)) / (1 + math.cos(math.pi * (k - 1) / T))
+        for g in self.groups:
+            g["lr"] = f * (g["lr"] - self.eta_min) + self.eta_min
+
+    def step(self, cur_iter: int):
+        gs = self.groups
+        if self.recover:
+            gs[1]["lr"] = self.past_lr
+        self._scheduler_step()
+        if self.recover is not None:
+            if cur_iter >= self.reduced_iter:
+                self.past_lr, self.recover = gs[1]["lr"], True
+                gs[1]["lr"] *= 0.5
+            else:
+                self.recover = False
+        if self.pre_training:
+            gs[0]["lr"] = gs[0]["initial_lr"] if cur_iter <= self.flow_fix else gs[1]["lr"] * self.pre_lr_ratio
+        if cur_iter < self.warmup_iter:
+            for g in gs:
+                g["lr"] = g["initial_lr"] / self.warmup_iter * cur_iter
+        return [g["lr"] for g in gs]
+
+    def state_dict(self):
+        return {k: getattr(self, k) for k in ("T_max", "last_restart", "epoch", "recover", "past_lr")}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            setattr(self, k, v)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # data-parallel gradient exchange
 # ---------------------------------------------------------------------------------------------------------
@@ -135,11 +213,14 @@ class GradBucketReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None, flat_grad: Optional[torch.Tensor] = None,
-                 offsets: Optional[List[int]] = None, optimizer=None):
+                 offsets: Optional[List[int]] = None, optimizer=None, single_rank_collectives: bool = False):
         """flat_grad / offsets (FlatAdamW.g / .offsets, `params` in that order): the gradients already live in one flat
-        buffer.  optimizer (a FlatAdamW): the same, plus the one-time re-layout by measured completion order."""
+        buffer.  optimizer (a FlatAdamW): the same, plus the one-time re-layout by measured completion order.
+        single_rank_collectives: issue every collective even in a process group of ONE rank (by default a lone rank skips them) --
+        the whole exchange path (communicator, ReduceOp.AVG, side stream, waits) then runs on a one-GPU box."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
         self.bucket_bytes = int(bucket_bytes)
         self.optimizer = optimizer
         if optimizer is not None:
@@ -200,7 +281,7 @@ class GradBucketReducer:
 
     def _launch(self, bi: int):
         b, flat = self.buckets[bi], self.flat[bi]
-        if self.world == 1:
+        if not self.active:
             return
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
@@ -242,7 +323,7 @@ class GradBucketReducer:
 
     def finish(self):
         """Wait for every bucket and leave the averaged gradients in p.grad."""
-        if self.world > 1:
+        if self.active:
             missing = [bi for bi, n in enumerate(self.pending) if n > 0]
             for bi in missing:  # parameters that received no gradient this step still take part (zeros)
                 for p in self.buckets[bi]:
@@ -270,6 +351,17 @@ class GradBucketReducer:
             return False
         seen = {id(p) for p in self._order_log}
         order = self._order_log + [p for p in self.params if id(p) not in seen]  # never-completed parameters go last
+        if self.active:
+            # every rank must cut the SAME buckets: rank 0's measured order is the order (a data-dependent branch -- frames_mirror -- or a
+            # parameter without a gradient on one rank would otherwise give equal-sized buckets that hold different parameters, and the
+            # in-place all-reduce would average unrelated tensors without any error).  torch DDP broadcasts its rebuilt buckets likewise.
+            idx_of = {id(p): i for i, p in enumerate(self.params)}  # (self.params: the optimizer's construction order, equal on all ranks)
+            dev = self.flat_grad.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            idx = torch.tensor([idx_of[id(p)] for p in order], dtype=torch.int64, device=dev)
+            dist.broadcast(idx, 0, group=self.group)
+            order = [self.params[i] for i in idx.tolist()]
+            if sorted(idx.tolist()) != list(range(len(self.params))):
+                raise RuntimeError("GradBucketReducer: rank 0's completion order is not a permutation of the parameters")
         self._order_log = []
         self._relaid = True
         self.optimizer.relayout(order)
@@ -278,9 +370,9 @@ class GradBucketReducer:
         return True
 
 
-def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, single_rank_collectives: bool = False):
     """Parameters AND buffers from rank `src` (what DDP does at wrap time; gamma_h/w, decay_v, spynet.mean/std included)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not single_rank_collectives):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src, group=group)
@@ -324,6 +416,7 @@ class FlatAdamW:
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
         self.params, self.offsets = params, offs
+        self.construction_order = list(params)  # what state_dict() is keyed on: group-major registration order, untouched by relayout()
         with torch.no_grad():
             for p, o in zip(params, offs):
                 view = self.p[o:o + p.numel()].view_as(p)
@@ -422,15 +515,50 @@ class FlatAdamW:
         self.advance()
         self.launch()
 
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_(all parameters, max_norm, norm_type=2) on the flat gradient buffer (tools/Trainer.py:141-143,
+        166-167): two launches, fixed summation order.  Returns a DEVICE tensor (total norm, applied coefficient); nothing is read on the host."""
+        from . import hip
+        lib = hip.lib()
+        ws = getattr(self, "_clip_ws", None)
+        if ws is None:
+            ws = self._clip_ws = torch.empty(int(lib.vmg_grad_clip_ws_bytes()), dtype=torch.uint8, device=self.g.device)
+            self._clip_out = torch.zeros(2, dtype=torch.float32, device=self.g.device)
+        hip.check(lib.vmg_grad_clip_norm(self.g.data_ptr(), self.n, float(max_norm), ws.data_ptr(), self._clip_out.data_ptr(), hip.stream_ptr()),
+                  "vmg_grad_clip_norm")
+        return self._clip_out
+
     def state_dict(self):
-        return {"t": self.t, "m": self.m, "v": self.v, "groups": [{k: g[k] for k in ("lr", "weight_decay", "initial_lr")} for g in self.groups]}
+        """Layout-independent: the moments are saved PER PARAMETER in construction order (group-major registration order), whatever
+        relayout() has done to the flat buffers since -- a checkpoint written after the data-parallel re-layout loads into a fresh
+        optimizer (registration-order layout) and the other way round."""
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        m, v = [], []
+        for p in self.construction_order:
+            o, n = off_of[id(p)], p.numel()
+            m.append(self.m[o:o + n].clone())
+            v.append(self.v[o:o + n].clone())
+        return {"t": self.t, "m": m, "v": v, "numel": [p.numel() for p in self.construction_order],
+                "groups": [{k: g[k] for k in ("lr", "weight_decay", "initial_lr")} for g in self.groups]}
 
     def load_state_dict(self, sd):
+        numel = [p.numel() for p in self.construction_order]
+        if not isinstance(sd.get("m"), (list, tuple)) or list(sd.get("numel", [])) != numel or len(sd["m"]) != len(numel) or len(sd["v"]) != len(numel):
+            raise ValueError("FlatAdamW.load_state_dict: the checkpoint's per-parameter moments do not match this optimizer's parameters "
+                             "(count / sizes in construction order)")
+        if len(sd["groups"]) != len(self.groups):
+            raise ValueError("FlatAdamW.load_state_dict: parameter group count differs")
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        with torch.no_grad():
+            for p, m, v in zip(self.construction_order, sd["m"], sd["v"]):
+                o, n = off_of[id(p)], p.numel()
+                if m.numel() != n or v.numel() != n:
+                    raise ValueError("FlatAdamW.load_state_dict: moment size mismatch")
+                self.m[o:o + n].copy_(m.reshape(-1))
+                self.v[o:o + n].copy_(v.reshape(-1))
         self.t = int(sd["t"])
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        for g, s in zip(self.groups, sd["groups"]):
-            g.update(s)
+        for g, s_ in zip(self.groups, sd["groups"]):
+            g.update(s_)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -441,7 +569,13 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), weight_decay: float = 0.0, eps_loss: float = 1e-12,
                  aux: bool = True, aux_ratio: float = 0.005, spynet_lr: float = 0.0, distributed: bool = False,
-                 bucket_bytes: int = 8 << 20):
+                 bucket_bytes: int = 8 << 20, schedule: Optional[dict] = None, grad_clip: Optional[float] = None,
+                 single_rank_collectives: bool = False):
+        """schedule: keyword arguments of LRSchedule (T_period, restarts, weights, eta_min, warmup_iter, flow_fix, pre_lr_ratio,
+        reduced_iter: the `train:` / `network.flow_fix` keys of the reference's configs) -- the learning rates are then updated after
+        every optimizer step like Trainer.update_learning_rate does; None keeps them constant.
+        grad_clip: max_norm of clip_grad_norm_ over ALL parameters before the optimizer step (train.if_grad_clip / grad_clip_up).
+        single_rank_collectives: see GradBucketReducer."""
         self.model = model
         from . import functional as FH
         FH.set_wgrad_mode("deferred")  # batched weight gradients written straight into the flat gradient buffer
@@ -456,16 +590,20 @@ class TrainStep:
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
             self.opt = FlatAdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
-            self.reducer = GradBucketReducer([], bucket_bytes, optimizer=self.opt) if distributed else None
+            self.reducer = GradBucketReducer([], bucket_bytes, optimizer=self.opt, single_rank_collectives=single_rank_collectives) if distributed else None
         else:  # host-side rehearsals only (the model itself has no CPU path)
             self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=0.0)
-            self.reducer = GradBucketReducer(model.parameters(), bucket_bytes) if distributed else None
+            self.reducer = GradBucketReducer(model.parameters(), bucket_bytes, single_rank_collectives=single_rank_collectives) if distributed else None
+        self.schedule = LRSchedule(self.opt.param_groups, **schedule) if schedule is not None else None
+        self.grad_clip = float(grad_clip) if grad_clip else None
+        self.iter = 0          # optimizer steps taken: the `cur_iter` of the reference's update_learning_rate
+        self.grad_norm = None  # device tensor (total norm, coefficient) of the last clipped step
         self.graph = None
         self._static = None
         self.grad_hook = None  # optional callable(TrainStep), run after the gradient exchange and before the optimizer (tests, logging)
         self.loss_args = dict(eps=eps_loss, aux=aux, aux_ratio=aux_ratio)
         if distributed:
-            broadcast_module_state(model)
+            broadcast_module_state(model, single_rank_collectives=single_rank_collectives)
 
     @staticmethod
     def _flush():
@@ -522,21 +660,39 @@ class TrainStep:
             self.graph.replay()
         return self._loss
 
-    def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
+    def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor, grad_acc: int = 1, update: bool = True) -> torch.Tensor:
+        """One sample (tools/Trainer.py:125-190).  grad_acc / update: gradient accumulation as in the reference's `revise_epoch` branch --
+        the loss is divided by grad_acc, gradients add up in the flat buffer over the micro-steps, and only the call with update=True
+        steps the optimizer, zeroes the gradients and advances the learning rates.  Unlike the reference (DDP all-reduces in every
+        micro-step's backward, tools/Trainer.py:160-190) the gradients are exchanged ONCE, during the updating micro-step's backward,
+        when the buffer holds the accumulated sum."""
         if self.graph is not None:
+            if grad_acc != 1 or not update:
+                raise RuntimeError("the captured step is one whole update; gradient accumulation runs eagerly")
             return self.replay(lrs, hrs)
-        return self._eager(lrs, hrs)
+        return self._eager(lrs, hrs, grad_acc, update)
 
-    def _eager(self, lrs: torch.Tensor, hrs: torch.Tensor) -> torch.Tensor:
+    def _eager(self, lrs: torch.Tensor, hrs: torch.Tensor, grad_acc: int = 1, update: bool = True) -> torch.Tensor:
+        if self.reducer is not None:
+            self.reducer.enabled = bool(update)
         out = self.model(lrs)
         if out.is_cuda and self.loss_args["aux"]:
             loss = charbonnier_edge_loss_hip(out.float(), hrs.float(), self.loss_args["eps"], self.loss_args["aux_ratio"])
         else:
             loss = charbonnier_edge_loss(out.float(), hrs.float(), **self.loss_args)
+        if grad_acc != 1:
+            loss = loss / grad_acc
         loss.backward()
         self._flush()
+        if not update:
+            return loss.detach()
         if self.reducer is not None:
             self.reducer.finish()
+        if self.grad_clip is not None:
+            if isinstance(self.opt, FlatAdamW):
+                self.grad_norm = self.opt.clip_grad_norm_(self.grad_clip)
+            else:
+                self.grad_norm = torch.nn.utils.clip_grad_norm_([p for g in self.opt.param_groups for p in g["params"]], self.grad_clip, norm_type=2)
         if self.grad_hook is not None:
             self.grad_hook(self)
         if isinstance(self.opt, FlatAdamW):
@@ -549,6 +705,9 @@ class TrainStep:
         else:
             self.opt.step()
         self.opt.zero_grad(set_to_none=True)
+        if self.schedule is not None:
+            self.schedule.step(self.iter)  # Trainer.update_learning_rate(step): the next step's learning rates
+        self.iter += 1
         if self.reducer is not None:
             self.reducer.relayout_by_completion()  # once, after the first step: buckets follow the measured completion order
         return loss.detach()
