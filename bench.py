@@ -182,7 +182,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and not distributed and args.workload == "train"
+    use_graph = args.graph and not distributed and args.workload != "infer"
     mode = "eager"
     if use_graph:
         try:

@@ -252,6 +252,10 @@ int vmg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mea
  * instead of by a separate pass */
 int vmg_layernorm_bwd_add(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, const void* add,
                           void* dx, float* dw, float* db, int64_t M, int C, void* stream);
+/* The same with ndy (1..5) gradients of the LayerNorm OUTPUT, summed in fp32 inside the kernel (a normalised tensor read by several consumers --
+ * the MorphFC mixer reads LayerNorm(x) five times -- gets one gradient per consumer; autograd would add them pairwise, three passes per add). */
+int vmg_layernorm_bwd_multi(int dtype, int ndy, const void* const* dy, const void* x, const float* mean, const float* rstd, const float* w,
+                            const void* add, void* dx, float* dw, float* db, int64_t M, int C, void* stream);
 
 /* ---- UpdownkeepSampling (reference: models/layers.py:777-798): the space<->depth rearrangement fused into the LayerNorm that follows it.
  * The LayerNorm rows are GATHERED from the feature map (forward) and their gradient is scattered back (backward); no rearranged

@@ -264,13 +264,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
+struct LnMore {
+  const void* p[4];
+  int n;
+};
+
 template <typename T, int V, int G, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, long long M, int C,
                                                             const LnMap map, const T* __restrict__ add, float* __restrict__ ws,
-                                                            unsigned int* __restrict__ counter) {
+                                                            unsigned int* __restrict__ counter, const LnMore more) {
+  // more: up to four FURTHER gradients of the LayerNorm output (contiguous rows, like dy): a normalised tensor that feeds several consumers
+  // (the MorphFC mixer reads LN2(x) five times: H branch, W branch, RCAB conv, RCAB residual, tanh gate) collects one gradient per consumer;
+  // they are summed here in fp32 on the way in -- autograd's pairwise adds cost three passes each over the (N, C) tensor.
   // add (optional, contiguous rows): a gradient that reaches the same tensor by a skip connection; dx = add + LayerNorm backward, so the
   // sum does not cost a pass of its own (the TAB residuals: x feeds the norm AND the residual add)
   const int nvec = C / V;
@@ -298,6 +306,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       if (vi < nvec) {
         nx[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, r, vi * V, C));
         ng[k] = reinterpret_cast<const VecN<T, V>*>(dy + r * C)[vi];
+        if (more.n) {  // (wave-uniform)
+          float acc[V];
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] = to_f32(ng[k].v[e]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < more.n) {
+              const VecN<T, V> t = reinterpret_cast<const VecN<T, V>*>(reinterpret_cast<const T*>(more.p[j]) + r * C)[vi];
+#pragma unroll
+              for (int e = 0; e < V; ++e) acc[e] += to_f32(t.v[e]);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < V; ++e) ng[k].v[e] = from_f32<T>(acc[e]);
+        }
       }
     }
   };
@@ -530,7 +553,7 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
 
 template <typename T, int V>
 static int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw, float* db,
-                    long long M, int C, hipStream_t st, const LnMap map, const void* add) {
+                    long long M, int C, hipStream_t st, const LnMap map, const void* add, const LnMore more) {
   const int nvec = C / V;
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
@@ -544,7 +567,7 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int nv = (nvec + G - 1) / G;
   unsigned int* counter = nullptr;
   float* ws = (blocks > LN_SUB && C <= 2048) ? ln_workspace(st, &counter) : nullptr;  // (null: plain float atomics on dw / db)
-#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add, ws, counter)
+#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add, ws, counter, more)
 #define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
   if (G == 16) LN_LAUNCH_G(16);
   else if (G == 32) LN_LAUNCH_G(32);
@@ -608,7 +631,7 @@ extern "C" int vmg_space_depth_ln_fwd(int dtype, int mode, const void* x, const 
 }
 
 static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* w, void* dx, float* dw,
-                       float* db, int64_t M, int C, void* stream, const LnMap map, int vmax, const void* add = nullptr) {
+                       float* db, int64_t M, int C, void* stream, const LnMap map, int vmax, const void* add = nullptr, const LnMore more = LnMore{{nullptr, nullptr, nullptr, nullptr}, 0}) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "layernorm_bwd: bad dtype");
   VMG_CHECK(dy && x && mean && rstd && w && dx && dw && db && M > 0 && C > 0, "layernorm_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -616,16 +639,16 @@ static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* me
   while (v > vmax) v >>= 1;
   if (dtype == VMG_BF16) {
     switch (v) {
-      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
-      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
-      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
-      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+      case 8: return ln_bwd_t<bf16, 8>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
+      case 4: return ln_bwd_t<bf16, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
+      case 2: return ln_bwd_t<bf16, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
+      default: return ln_bwd_t<bf16, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
     }
   }
   switch (v) {
-    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
-    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
-    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add);
+    case 4: return ln_bwd_t<float, 4>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
+    case 2: return ln_bwd_t<float, 2>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
+    default: return ln_bwd_t<float, 1>(dy, x, mean, rstd, w, dx, dw, db, M, C, st, map, add, more);
   }
 }
 
@@ -638,6 +661,18 @@ extern "C" int vmg_layernorm_bwd_add(int dtype, const void* dy, const void* x, c
                                      const void* add, void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
   VMG_CHECK(!add || (uintptr_t)add % 16 == 0, "layernorm_bwd_add: add must be 16-byte aligned");
   return ln_bwd_impl(dtype, dy, x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{0, 0, 0, 0}, 8, add);
+}
+
+extern "C" int vmg_layernorm_bwd_multi(int dtype, int ndy, const void* const* dy, const void* x, const float* mean, const float* rstd, const float* w,
+                                       const void* add, void* dx, float* dw, float* db, int64_t M, int C, void* stream) {
+  VMG_CHECK(dy && ndy >= 1 && ndy <= 5, "layernorm_bwd_multi: 1 to 5 output gradients");
+  LnMore more{{nullptr, nullptr, nullptr, nullptr}, ndy - 1};
+  for (int i = 0; i < ndy; ++i) {
+    VMG_CHECK(dy[i] && (uintptr_t)dy[i] % 16 == 0, "layernorm_bwd_multi: gradient %d is null or not 16-byte aligned", i);
+    if (i) more.p[i - 1] = dy[i];
+  }
+  VMG_CHECK(!add || (uintptr_t)add % 16 == 0, "layernorm_bwd_multi: add must be 16-byte aligned");
+  return ln_bwd_impl(dtype, dy[0], x, mean, rstd, w, dx, dw, db, M, C, stream, LnMap{0, 0, 0, 0}, 8, add, more);
 }
 
 extern "C" int vmg_space_depth_ln_bwd(int dtype, int mode, const void* dy, const void* x, const float* mean, const float* rstd, const float* w,

@@ -83,16 +83,29 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const T* __restrict__
   }
 }
 
-// out[g, i] = scale * sum over the group's chunks, in chunk order, of partial[g][chunk][i]; `width` = C (or 3C for group_reduce3).
+// out[g, i] = scale * sum over the group's chunks of partial[g][chunk][i]; `width` = C (or 3C for group_reduce3).  One block per (group, 16
+// columns): 16 row groups x 16 columns of threads, row group q adds the chunks q, q + 16, ... in that order (64-byte reads, all issued
+// up front), the 16 row-group sums are then added in index order through LDS -- a FIXED summation tree, independent of arrival order.
 __global__ __launch_bounds__(256) void group_reduce_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int G, int chunks, int width,
                                                                  float scale) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= G * width) return;
-  const int g = i / width, c = i - g * width;
-  const float* p = partial + (long long)g * chunks * width + c;
+  __shared__ float sm[16][17];
+  const int slabs = (width + 15) >> 4;
+  const int g = blockIdx.x / slabs, c = (blockIdx.x - g * slabs) * 16 + (threadIdx.x & 15);
+  const int q = threadIdx.x >> 4;
   float t = 0.f;
-  for (int k = 0; k < chunks; ++k) t += p[(long long)k * width];
-  out[i] = t * scale;
+  if (c < width) {
+    const float* p = partial + (long long)g * chunks * width + c;
+#pragma unroll 4
+    for (int k = q; k < chunks; k += 16) t += p[(long long)k * width];
+  }
+  sm[q][threadIdx.x & 15] = t;
+  __syncthreads();
+  if (q == 0 && c < width) {
+    float u = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u += sm[i][threadIdx.x & 15];
+    out[(long long)g * width + c] = u * scale;
+  }
 }
 
 // out (G, C, 3) += scale * sum_r a * {b0, b1, b2}: the three branch sums of the MorphFC re-weighting backward (d softmax-weights) from ONE
@@ -497,7 +510,7 @@ extern "C" int vmg_group_reduce(int dtype, const void* a, const void* b, const v
                          ws, G, (long long)R, C, mode, scale, chunks);
   }
   VMG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(cdiv(G * C, 256)), dim3(256), 0, st, (const float*)ws, out, G, chunks, C, scale);
+  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(G * cdiv(C, 16)), dim3(256), 0, st, (const float*)ws, out, G, chunks, C, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }
@@ -518,7 +531,7 @@ extern "C" int vmg_group_reduce3(int dtype, const void* a, const void* b0, const
     hipLaunchKernelGGL((group_reduce3_kernel<float, 4>), dim3(G * chunks), dim3(256), 0, st, (const float*)a, (const float*)b0, (const float*)b1,
                        (const float*)b2, ws, G, (long long)R, C, scale, chunks);
   VMG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(cdiv(G * C * 3, 256)), dim3(256), 0, st, (const float*)ws, out, G, chunks, 3 * C, scale);
+  hipLaunchKernelGGL(group_reduce_final_kernel, dim3(G * cdiv(3 * C, 16)), dim3(256), 0, st, (const float*)ws, out, G, chunks, 3 * C, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -70,10 +70,11 @@ def bump_weight_epoch():
 
 
 def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
-           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None, deep: int = 0) -> K.PackedConv:
+           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None, deep: int = 0, orange: Optional[Sequence[int]] = None) -> K.PackedConv:
     """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
-    needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8)."""
-    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles, deep == 3)
+    needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8).
+    orange = (o0, no): one GROUP of a grouped convolution -- forward: only the outputs O[o0:o0+no); data gradient: K = O[o0:o0+no) (no % 8 == 0)."""
+    key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles, deep == 3, tuple(orange) if orange else None)
     ver = (weight._version, _WEIGHT_EPOCH[0])
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2] is weight:
@@ -105,12 +106,24 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
                 po += _pad_to(c)
             w = wp
             src_ch = [_pad_to(c) for c in src_ch]
+        o0, no = (orange[0], orange[1]) if orange else (0, None)
         if deep == 3:
-            pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles)
+            pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no)
         else:
-            pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles)
+            pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no)
     elif kind == "dgrad":
         on = I - i0 if on is None else on
+        if orange:
+            if orange[1] % 8:
+                raise HipError("grouped data-gradient pack: the group's output channel count must be a multiple of 8")
+            if deep == 3:
+                pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]])
+            else:
+                pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]])
+            if key not in _PACK_VOLATILE and pw.call is not None and pw.call[0] == weight.data_ptr():
+                _PACK_STAMP[0] += 1
+            _PACK_CACHE[key] = [ver, pw, weight]
+            return pw
         if O % 8:
             wp = w.new_zeros(_pad_to(O), *w.shape[1:])
             wp[:O].add_(w)  # (an add kernel into the zeros: a contiguous copy_ would be a memcpy node, see the forward pack)
@@ -317,9 +330,10 @@ class _DeferredWgrad:
             else:
                 self.uses[key] = left
 
-    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0):
+    def add(self, weight, bias, srcs, src_ch, dpre, ks, N, H, W, scale: float = 1.0, gen: int = 0, o0: int = 0):
+        """o0: first output channel of this use (a group of a grouped convolution writes rows o0 .. o0 + dpre channels of the gradient)."""
         ent = self.pending.setdefault(id(weight), [weight, bias, []])
-        ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale)))
+        ent[2].append((srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale), int(o0)))
         self.bw_gen = gen
         if not self._queued:  # whatever is still pending when this backward() call ends is completed then
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
@@ -368,6 +382,8 @@ class _DeferredWgrad:
         ks = e0[3]
         if len(e0[1]) != 1 or ks not in (1, 3) or weight.shape[1] != e0[1][0] or (ks == 3 and weight.dim() != 4):
             return None
+        if any(e[8] for e in entries) or e0[2].shape[-1] != weight.shape[0]:
+            return None  # (groups of a grouped convolution: the general batched kernel, per output-row range)
         x0, d0 = e0[0][0], e0[2]
         if x0.shape[-1] != e0[1][0] or not K.conv_wgrad3_multi_ok(x0, d0, ks):
             return None
@@ -422,13 +438,13 @@ def _wgrad_entries(entries, dW, db):
     """dW (+= ) the weight gradient of every recorded (sources, src_ch, dpre, ks, N, H, W, scale) entry, batched by shape."""
     groups = {}
     for e in entries:
-        sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]), e[7])
+        sig = (e[1], e[3], e[4], e[5], e[6], e[2].dtype, tuple(e[2].shape[-1:]), e[7], e[8] if len(e) > 8 else 0)
         groups.setdefault(sig, []).append(e)
-    for (src_ch, ks, N, H, W, _, _, scale), es in groups.items():
+    for (src_ch, ks, N, H, W, _, _, scale, o0), es in groups.items():
         off = 0
         for i, c in enumerate(src_ch):
             xs = [e[0][i][..., :c] if e[0][i].shape[-1] != c else e[0][i] for e in es]
-            K.conv_wgrad_batched(xs, [e[2] for e in es], dW, db if i == 0 else None, ks, N, H, W, scale=scale, i0=off)
+            K.conv_wgrad_batched(xs, [e[2] for e in es], dW, db if i == 0 else None, ks, N, H, W, scale=scale, i0=off, o0=o0)
             off += c
 
 
@@ -436,7 +452,7 @@ def _wgrad_now(weight, bias_needed: bool, srcs, src_ch, dpre, ks, N, H, W, scale
     """(dW, db) of one use, as fresh fp32 tensors (mode 'autograd')."""
     dW = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
     db = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device) if bias_needed else None
-    _wgrad_entries([(srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale))], dW, db)
+    _wgrad_entries([(srcs, tuple(src_ch), dpre, ks, N, H, W, float(scale), 0)], dW, db)
     return dW, db
 
 
@@ -557,6 +573,84 @@ def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[to
     """Channels-last convolution / linear over N*H*W pixels; srcs are virtually concatenated along channels."""
     cfg = (ks, act, float(slope), float(alpha), bool(pixel_shuffle), int(N), int(H), int(W))
     return _Conv2d.apply(weight, bias, res, cfg, *srcs)
+
+
+class _GroupedConv2d(_Fn):
+    """act(conv(x, weight, groups) + bias): nn.Conv2d(C, O, ks, groups=G) on channels-last x (N,H,W,C) as G launches of the convolution kernel
+    that all address the PARAMETER itself (output rows / K range of the group in the pack), write channel slices of ONE output tensor, and
+    record their (input, output-gradient) pairs with the group's row offset -- no weight or activation slices go through autograd (round 2
+    ran the groups as separate convolutions on sliced tensors: a pack kernel per group and call, a concatenation, four zero-filled slice
+    gradients per tensor; reference: Mlp_cnn.fc1 with n_groups = 4, models/function.py:50-79)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        G, ks, act, slope, N, H, W = cfg
+        O, cg = weight.shape[0], weight.shape[1]
+        og, dt, M = O // G, x.dtype, N * H * W
+        ctx.x_shape = tuple(x.shape)
+        x = x.contiguous()
+        cgp = _pad_to(cg)
+        if cgp != cg:  # groups whose channel count is no multiple of 8 (112 / 4 = 28): ONE padded copy (N,H,W,G,cgp), group g = a strided channel slice
+            xp = torch.nn.functional.pad(x.reshape(N, H, W, G, cg), (0, cgp - cg))
+            srcs = [xp[..., g, :] for g in range(G)]
+        else:
+            xf = x.reshape(N, H, W, G * cg)
+            srcs = [xf[..., g * cg:(g + 1) * cg] for g in range(G)]
+        out = torch.empty((N, H, W, O), dtype=dt, device=x.device)
+        need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
+        pre = torch.empty_like(out) if need_pre else None
+        tiles, mt, deep = choose_tiling(M, og, ks, dt, [cgp])
+        for g in range(G):
+            pw = packed(weight, dt, "fwd", [cg], tiles=tiles, deep=deep, orange=(g * og, og))
+            K.conv_forward([srcs[g]], pw, None if bias is None else bias[g * og:(g + 1) * og], N, H, W, act=act, slope=slope,
+                           out=out[..., g * og:(g + 1) * og], out_pre=None if pre is None else pre[..., g * og:(g + 1) * og], mt=mt, deep=deep)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[1] and \
+            (bias is None or isinstance(bias, torch.nn.Parameter))
+        if ctx.defer:
+            for _ in range(G):
+                ctx.gen = DEFERRED.note_use(weight, bias)
+            ctx.bias_ref = bias
+        ctx.srcs = srcs  # (views of x / of its padded copy: kept for the weight gradient)
+        ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        G, ks, act, slope, N, H, W = ctx.cfg
+        weight, y, pre = ctx.saved_tensors
+        srcs = ctx.srcs
+        O, cg = weight.shape[0], weight.shape[1]
+        og, M = O // G, N * H * W
+        dpre = _act_grad(dy.contiguous(), y, pre, act, slope, 1.0)
+        dt = dpre.dtype
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, H, W, G * cg), dtype=dt, device=dy.device)
+            tiles, mt, deep = choose_tiling(M, cg, ks, dt, [og])
+            for g in range(G):
+                pw = packed(weight, dt, "dgrad", None, 0, cg, tiles=tiles, deep=deep, orange=(g * og, og))
+                K.conv_forward([dpre[..., g * og:(g + 1) * og]], pw, None, N, H, W, out=dx[..., g * cg:(g + 1) * cg], mt=mt, deep=deep)
+        d_w = d_b = None
+        if ctx.defer:
+            for g in range(G):
+                DEFERRED.add(weight, ctx.bias_ref, [srcs[g]], [cg], dpre[..., g * og:(g + 1) * og], ks, N, H, W, gen=ctx.gen, o0=g * og)
+        elif ctx.needs_input_grad[1]:
+            d_w = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+            d_b = torch.zeros(O, dtype=torch.float32, device=weight.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            _wgrad_entries([([srcs[g]], (cg,), dpre[..., g * og:(g + 1) * og], ks, N, H, W, 1.0, g * og) for g in range(G)], d_w, d_b)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            d_b = dpre.float().reshape(-1, O).sum(0)
+        return (dx.reshape(ctx.x_shape) if dx is not None else None), d_w, d_b, None
+
+
+def grouped_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], groups: int, N: int, H: int, W: int, ks: int = 3,
+                   act: int = hip.ACT_NONE, slope: float = 0.0) -> torch.Tensor:
+    """nn.Conv2d(C, O, ks, padding=ks//2, groups=groups) + activation on channels-last x covering N*H*W pixels -> (N,H,W,O)."""
+    if weight.shape[0] % groups or x.shape[-1] != groups * weight.shape[1] or (weight.shape[0] // groups) % 8:
+        raise HipError("grouped_conv2d: channels must divide into the groups (output channels per group a multiple of 8)")
+    return _GroupedConv2d.apply(x, weight, bias, (int(groups), int(ks), int(act), float(slope), int(N), int(H), int(W)))
 
 
 class _ResidualChain(_Fn):
@@ -777,6 +871,45 @@ class _LayerNormSkip(_Fn):
 def layer_norm_skip(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
     """(nn.LayerNorm(x), x) with the skip gradient summed inside the LayerNorm backward kernel."""
     return _LayerNormSkip.apply(x, w, b, eps)
+
+
+class _LayerNormFan(_Fn):
+    """(y_1 .. y_n, x): n handles of the SAME LayerNorm(x) for n consumers, and x for the skip connection.  Autograd hands this node's backward
+    all n output gradients at once; the LayerNorm backward kernel sums them (and the skip gradient) while it reads them
+    (vmg_layernorm_bwd_multi) -- the n - 1 full-size adds autograd would issue for a tensor with n consumers never run."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, n):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_forward(x, w, b, eps)
+        ctx.save_for_backward(x, mean, rstd, w)
+        ctx.direct = DEFERRED.direct(w, b)
+        if ctx.direct:
+            ctx.params, ctx.gen = (w, b), DEFERRED.note_params(w, b)
+        ctx.set_materialize_grads(False)
+        return (*[y.view_as(y) for _ in range(n)], x.view_as(x))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, mean, rstd, w = ctx.saved_tensors
+        dys = [g for g in grads[:-1] if g is not None]
+        dskip = grads[-1]
+        if not dys:  # (the normalised branch is unused)
+            if ctx.direct:
+                DEFERRED.written(ctx.gen, *ctx.params)
+            return dskip, None, None, None, None
+        into = tuple(DEFERRED.grad_of(p) for p in ctx.params) if ctx.direct else None
+        dx, dw, db = K.layernorm_backward(dys, x, mean, rstd, w, into=into, add=dskip)
+        if ctx.direct:
+            DEFERRED.written(ctx.gen, *ctx.params)
+            return dx, None, None, None, None
+        return dx, dw, db, None, None
+
+
+def layer_norm_fan(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, n: int):
+    """([LayerNorm(x)] * n, x): see _LayerNormFan (n <= 5)."""
+    out = _LayerNormFan.apply(x, w, b, eps, int(n))
+    return list(out[:-1]), out[-1]
 
 
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -384,12 +384,28 @@ def _grad_pair(C: int, device, into):
     return dw, db
 
 
-def layernorm_backward(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None, add=None):
+def layernorm_backward(dy, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, w: torch.Tensor, into=None, add=None):
     """into = (dw, db): the kernel's atomic sums are ADDED to these buffers (param.grad) instead of to fresh zero tensors.
-    add: a gradient of x's shape that is summed into dx by the kernel (the skip-connection gradient)."""
-    hip.require_cuda(dy, x, mean, rstd, w, add)
+    add: a gradient of x's shape that is summed into dx by the kernel (the skip-connection gradient).
+    dy: one gradient, or a list of up to five gradients of the LayerNorm output that the kernel sums on the way in."""
     C = x.shape[-1]
     M = x.numel() // C
+    if isinstance(dy, (list, tuple)):
+        dys = [d.contiguous() for d in dy]
+        hip.require_cuda(x, mean, rstd, w, add, *dys)
+        if not 1 <= len(dys) <= 5 or any(d.shape != x.shape or d.dtype != x.dtype for d in dys):
+            raise HipError("layernorm_backward: 1..5 output gradients of x's shape and dtype expected")
+        dx = torch.empty_like(x)
+        dw, db = _grad_pair(C, x.device, into)
+        if add is not None:
+            if add.shape != x.shape or add.dtype != x.dtype:
+                raise HipError("layernorm_backward: add must have x's shape and dtype")
+            add = add.contiguous()
+        hip.check(hip.lib().vmg_layernorm_bwd_multi(hip.dtype_code(x.dtype), len(dys), _ptrs(dys), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w.data_ptr(),
+                                                    add.data_ptr() if add is not None else None, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, C,
+                                                    hip.stream_ptr()), "vmg_layernorm_bwd_multi")
+        return dx, dw, db
+    hip.require_cuda(dy, x, mean, rstd, w, add)
     dy = dy.contiguous()
     dx = torch.empty_like(x)
     dw, db = _grad_pair(C, x.device, into)

@@ -158,13 +158,15 @@ class RCAB(nn.Module):
         self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat, 3, 1, 1), nn.ReLU(), nn.Conv2d(n_feat, n_feat, 3, 1, 1),
                                   _CALayer(n_feat, reduction))
 
-    def forward(self, x, out_scale: float = 1.0):
+    def forward(self, x, out_scale: float = 1.0, x_res=None):
+        """x_res: a second autograd handle of x for the residual add (functional.layer_norm_fan: the two gradients w.r.t. x are then summed
+        by the LayerNorm backward kernel instead of by an add pass of their own)."""
         B, T, H, W, C = x.shape
         N = B * T
         r = conv(self.body[0], [x], N, H, W, act=ACT_RELU)
         r = conv(self.body[2], [r], N, H, W)
         du = self.body[3].conv_du
-        return FH.channel_attention_residual(r, x.reshape(N, H, W, C), du[0].weight, du[0].bias, du[2].weight, du[2].bias,
+        return FH.channel_attention_residual(r, (x if x_res is None else x_res).reshape(N, H, W, C), du[0].weight, du[0].bias, du[2].weight, du[2].bias,
                                              out_scale).reshape(B, T, H, W, C)
 
 
@@ -196,10 +198,7 @@ class Mlp_cnn(nn.Module):
         if self.n_groups == 1:
             h = conv(self.fc1, [x], N, H, W, act=ACT_GELU)
         else:
-            G, cg, og = self.n_groups, C // self.n_groups, self.hidden_features // self.n_groups
-            parts = [FH.conv2d([x[..., g * cg:(g + 1) * cg]], self.fc1.weight[g * og:(g + 1) * og], self.fc1.bias[g * og:(g + 1) * og],
-                               N, H, W, ks=3, act=ACT_GELU) for g in range(G)]
-            h = torch.cat(parts, -1)
+            h = FH.grouped_conv2d(x, self.fc1.weight, self.fc1.bias, self.n_groups, N, H, W, ks=3, act=ACT_GELU)
         return lin(self.fc2, h, res=res).reshape(B, T, H, W, C)
 
 
@@ -226,7 +225,12 @@ class Enhanced_MorphFCs_decay(nn.Module):
         self.register_buffer("gamma_h", decay_gamma(chunk_h, self.Ch))
         self.register_buffer("gamma_w", decay_gamma(chunk_w, self.Cw))
 
+    N_HANDLES = 5  # consumers of the mixer's input: H branch, W branch, channel branch (RCAB: conv + residual), tanh gate
+
     def forward(self, x):
+        """x: the normalised features (B,T,H,W,C), or a list of N_HANDLES autograd handles of them (functional.layer_norm_fan)."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x] * self.N_HANDLES
+        x = xs[0]
         B, T, H, W, C = x.shape
         if getattr(self, "_t1_done", False):  # (VMG.forward has applied this call's decay for all mixers at once, FH.decay_weights_and_repack)
             self._t1_done = False
@@ -235,16 +239,16 @@ class Enhanced_MorphFCs_decay(nn.Module):
                 self.mlp_h[0].weight.mul_(self.gamma_h)
                 self.mlp_w[0].weight.mul_(self.gamma_w)
         # token reshuffle + Linear + ReLU + 1/Ch + inverse reshuffle: one kernel per branch where it is instantiated
-        h = FH.morph_linear(x, self.mlp_h[0].weight, self.mlp_h[0].bias, "h", self.chunk_h, self.Ch)
-        w = FH.morph_linear(x, self.mlp_w[0].weight, self.mlp_w[0].bias, "w", self.chunk_w, self.Cw)
+        h = FH.morph_linear(xs[0], self.mlp_h[0].weight, self.mlp_h[0].bias, "h", self.chunk_h, self.Ch)
+        w = FH.morph_linear(xs[1], self.mlp_w[0].weight, self.mlp_w[0].bias, "w", self.chunk_w, self.Cw)
         if isinstance(self.mlp_c, RCAB):
-            c = self.mlp_c(x, out_scale=1.0 / C)
+            c = self.mlp_c(xs[2], out_scale=1.0 / C, x_res=xs[3])
         else:
-            c = lin(self.mlp_c[0], x, act=ACT_RELU, alpha=1.0 / C)
+            c = lin(self.mlp_c[0], xs[2], act=ACT_RELU, alpha=1.0 / C)
         rw = self.reweight
         y = FH.reweight_mix(h, w, c, rw.fc1.weight, rw.fc1.bias, rw.fc2.weight, rw.fc2.bias)
         y = lin(self.proj, y)
-        return FH.tanh_gate(x, y)
+        return FH.tanh_gate(xs[4], y)
 
 
 def decay_gamma(chunk: int, ch_total: int) -> torch.Tensor:
@@ -284,7 +288,12 @@ class TAB(nn.Module):
         s = self.spatial_scale
         dp = self.drop_prob > 0.0 and self.training
         # x feeds the norm AND the residual: layer_norm_skip hands x back so that both gradients meet in the LayerNorm backward kernel
-        n2, xs = FH.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        # ... and the mixer reads the normalised tensor five times: layer_norm_fan hands out one autograd handle per consumer, so that ALL their
+        # gradients (and the skip gradient) are summed inside the one LayerNorm backward kernel
+        if torch.is_grad_enabled() and x.requires_grad:
+            n2, xs = FH.layer_norm_fan(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, Enhanced_MorphFCs_decay.N_HANDLES)
+        else:
+            n2, xs = FH.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         y = self.spatial_mixing(n2)
         x = FH.residual_drop_path(xs, y, self.drop_prob, self.training, s)  # one pass: mask, scale and add
         n3, xs = FH.layer_norm_skip(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)

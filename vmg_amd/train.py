@@ -624,8 +624,14 @@ class TrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            # warm up until the set of cached weight packs has settled: a pack whose weight is modified in place between optimizer steps (the
+            # MorphFC decay) is recognised in the SECOND step and joins the one-launch repack plans in the third; a plan that is rebuilt inside
+            # the capture would upload its entries there (a host-to-device copy: not capturable)
+            for i in range(max(warmup, 8)):
+                stamp = FH._PACK_STAMP[0]
                 self._eager(*self._static)
+                if i + 1 >= warmup and FH._PACK_STAMP[0] == stamp and FH._VOL_STATE["stamp"] == stamp and FH._PACK_STATE["stamp"] == stamp:
+                    break
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if not isinstance(self.opt, FlatAdamW):
