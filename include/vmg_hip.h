@@ -409,6 +409,35 @@ int vmg_tile_finalize(const float* E, const float* Wt, float* out_f32, unsigned 
 int vmg_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2, float eps,
                    void* stream);
 
+/* ---- fp8 (OCP e4m3) 3x3 convolution on the block-scaled matrix instruction (BASELINE configs[4] "fp8 MFMA weights"; the
+ * reference computes the same convolutions in fp32: models/trajectory.py:16-52, 165-221) ------------------------------------------------
+ * Q8 RECORD of a pixel with C channels: [32*ceil(C/32) bytes e4m3, zero beyond C][16 bytes: an E8M0 scale byte per 32-channel block, rest
+ * zero]; value = e4m3 * 2^(scale - 127); vmg_q8_record_bytes(C) bytes per pixel (176 for C = 144, 144 for C = 112).
+ *   vmg_q8_quantize     bf16 rows (M pixels, pixel stride x_ps elements) -> records (block scale: the power of two mapping the block's largest
+ *                       magnitude into (224, 448]).
+ *   vmg_convq8_pack     fp32 (O, I, 3, 3) -> e4m3 k-step images of the instruction's A operand + one E8M0 scale byte per output channel
+ *                       (transpose_flip: the data-gradient form); vmg_convq8_pack_bytes(Cout, Cin) bytes.  144 -> 144 and 112 -> 112.
+ *   vmg_convq8_fwd      out = [res +] alpha * act(conv3x3(src records) + bias), fp32 accumulation; written as bf16 rows (out, optional) and / or
+ *                       as records for the next convolution (outq, optional; quantised from the bf16-rounded values when both are written). */
+typedef struct vmg_convq8_desc {
+  int N, H, W, Cin, Cout;
+  const void* src;     /* (N,H,W) records, vmg_q8_record_bytes(Cin) bytes each */
+  const void* packed;  /* vmg_convq8_pack image */
+  const float* bias;   /* (Cout) or null */
+  void* out;           /* bf16 (N,H,W,out_ps) or null */
+  int64_t out_ps;
+  void* outq;          /* records (N,H,W) x vmg_q8_record_bytes(Cout), or null */
+  const void* res;     /* bf16 residual or null */
+  int64_t res_ps;
+  int act;             /* 0 none, 1 relu, 2 leaky relu (slope) */
+  float slope, alpha;
+} vmg_convq8_desc;
+int vmg_q8_record_bytes(int C);
+int vmg_q8_quantize(const void* x, int64_t x_ps, void* out, int64_t M, int C, void* stream);
+int64_t vmg_convq8_pack_bytes(int Cout, int Cin);
+int vmg_convq8_pack(const float* w, int O, int I, int transpose_flip, void* packed, void* stream);
+int vmg_convq8_fwd(const vmg_convq8_desc* d, void* stream);
+
 /* ---- clip_grad_norm_ over a flat fp32 gradient buffer (reference: torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) as
  * called in tools/Trainer.py:141-143, 166-167 when train.if_grad_clip is set) -------------------------------------------------
  * g: n floats, 16-byte aligned; workspace: vmg_grad_clip_ws_bytes() bytes of device memory; norm_out (DEVICE, 2 floats): the total

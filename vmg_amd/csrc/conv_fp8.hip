@@ -1,0 +1,504 @@
+// fp8 (OCP e4m3) 3x3 convolution on the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 (SURVEY 8f-4 / BASELINE configs[4]:
+// "fp8 MFMA weights"; no reference anchor -- the reference computes these convolutions in fp32, models/trajectory.py:16-52, 165-221).
+//
+// Data formats
+//   * activations travel as Q8 RECORDS: per pixel [DB = 32*ceil(C/32) bytes of e4m3 values, zero beyond C][16 bytes: one E8M0 scale byte per
+//     32-channel block, rest zero] -- 176 bytes for C = 144 (bf16: 288), 144 for C = 112.  value = e4m3 * 2^(scale - 127).  A record is
+//     written by the PRODUCING convolution's epilogue (or by vmg_q8_quantize from a bf16 tensor): block scale = the power of two that maps
+//     the block's largest magnitude into (224, 448].
+//   * weights are packed per k-step as the instruction's A operand with ONE E8M0 scale per output channel (vmg_convq8_pack).
+// The instruction (probed on gfx950, tools/ubench/mfma_f8_probe*.cpp): lane l supplies row / column l & 15 and 32 operand bytes; byte j of lane
+// group g = l >> 4 meets byte j of group g of the other operand; a 32-element scale block is bytes [0,16) of groups 2p, 2p+1 (p = 0, 1) or
+// bytes [16,32) of them (blocks 2, 3), and block b takes its scale from the scale register of lane group b.  A k-step therefore covers FOUR
+// (tap, 32-channel block) SLOTS: lane group g reads 16 bytes of slot g >> 1 and 16 bytes of slot 2 + (g >> 1) (channel half g & 1), and
+// supplies the scale byte of slot g.  Products are exact; the adder tree keeps ~14 bits below the largest product of an instruction.
+// The instruction takes 32 cycles per SIMD for K = 128 where v_mfma_f32_16x16x32_bf16 takes 16 for K = 32: twice the rate.
+//
+// Kernel structure = the weight-streaming kernel's (conv_igemm.hip::conv_ws_kernel): ONE workgroup per 128-pixel tile (8 rows x 16 columns)
+// and all output channels; waves 0..3 consume (wave w: pixel rows 2w, 2w+1 x all channel tiles), waves 4..6 stream the packed weights through a
+// 4-slot LDS ring by LDS-DMA (a stage = one k-step = NCT*2 KiB); the halo tile of records is copied by the consumers at the start.  The
+// consumers keep a whole k-step of weight fragments in registers: the fragments of k-step t+1 are read from LDS while the MFMAs of k-step t run
+// (tile by tile, each read right behind the MFMAs that used its registers), so a stage barrier never waits for LDS.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ uint4 g_q8_zero16;  // 16 zero bytes: source of out-of-image lanes of the halo copy (a zero record = zero values)
+
+struct ConvQ {
+  const char* src;              // (N,H,W) records of REC bytes
+  const char* wpack;            // [NK][KSB] e4m3 image, then COB scale bytes
+  const float* bias;            // (Cout) or null
+  bf16* out;                    // optional bf16 output (N,H,W,out_ps)
+  long long out_ps;
+  char* outq;                   // optional record output (N,H,W) x REC_OUT bytes
+  const bf16* res;              // optional residual (bf16)
+  long long res_ps;
+  int N, H, W, Cout, tiles_x, tiles_y;
+  int act;
+  float slope, alpha;
+  int halo_bytes;
+};
+
+template <int NCT, int NCH>
+struct QGeo {
+  static constexpr int COB = NCT * 16;        // output channels (one block)
+  static constexpr int KSB = COB * 128;       // bytes of one k-step image [2 halves][4 lane groups][COB][16]
+  static constexpr int NSLOT = 9 * NCH;       // (tap, 32-channel block) slots
+  static constexpr int NK = (NSLOT + 3) / 4;  // k-steps
+  static constexpr int DBI = NCH * 32, REC = DBI + 16;
+  static constexpr int NOC = (COB + 31) / 32, DBO = NOC * 32, REC_OUT = DBO + 16;
+  static constexpr int THREADS = 448;
+  static constexpr int NP = KSB / 1024, P0 = (NP + 2) / 3, P2 = NP - 2 * P0;  // 1-KiB pieces of a stage per loader wave (waves 0, 1: P0; wave 2: P2)
+  static constexpr int PSTR = COB * 4 + 16;   // bytes per pixel of the fp32 epilogue patch
+  static constexpr int NITEM = 128 * NOC, NIT = (NITEM + THREADS - 1) / THREADS;
+  static_assert(KSB % 1024 == 0 && P2 > 0, "stage pieces");
+};
+
+// byte offset (inside the halo tile, relative to the lane's pixel) of slot s: tap row / column shift, plus the block's data / scale byte
+template <int NCH>
+__device__ __forceinline__ constexpr int q_tap_pix(int s) { return s < 9 * NCH ? ((s / NCH) / 3) * 18 + (s / NCH) % 3 : 0; }
+template <int NCH>
+__device__ __forceinline__ constexpr int q_chunk(int s) { return s < 9 * NCH ? s % NCH : 0; }
+
+template <int NCT, int NCH>
+__global__ __launch_bounds__(448, 2) void convq8_kernel(const ConvQ a) {
+  using G = QGeo<NCT, NCH>;
+  constexpr int COB = G::COB, KSB = G::KSB, NK = G::NK, REC = G::REC, DBI = G::DBI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* ring = smem + a.halo_bytes;
+  float* lbias = reinterpret_cast<float*>(ring + 4 * KSB);
+  unsigned char* lwsc = reinterpret_cast<unsigned char*>(lbias + COB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = gridDim.x;
+  const int bid = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // XCD-contiguous tile order (speed only)
+  const int tx = bid % a.tiles_x;
+  const int rr = bid / a.tiles_x;
+  const int ty = rr % a.tiles_y, n = rr / a.tiles_y;
+  const long long tile_pix = ((long long)n * a.H + ty * 8) * a.W + tx * 16;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    const int lw = wave - 4;
+    const int np = lw == 2 ? G::P2 : G::P0;
+    const char* wsrc = a.wpack + lw * G::P0 * 1024 + lane * 16;
+    auto issue_stage = [&](int t) {
+      const char* gsrc = wsrc + (long long)t * KSB;
+      char* dst = ring + (t & 3) * KSB + lw * G::P0 * 1024;
+#pragma unroll
+      for (int i = 0; i < G::P0; ++i)
+        if (i < np) __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc + i * 1024), LDS_PTR(dst + i * 1024), 16, 0, 0);
+    };
+    auto wait_one_in_flight = [&]() {  // everything but the youngest stage has landed
+      if (lw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::P0) : "memory");
+    };
+    {
+      const int c = tid - 256;  // bias and weight scales -> LDS (read by the consumers behind B_0)
+      if (c < COB) {
+        lbias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+        lwsc[c] = reinterpret_cast<const unsigned char*>(a.wpack + (long long)NK * KSB)[c];
+      }
+    }
+    issue_stage(0);
+    if (NK > 1) issue_stage(1);
+    if (NK > 1) wait_one_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B_0: stage 0, bias, scales (and the consumers' halo) are in LDS
+#pragma unroll 1
+    for (int t = 0; t < NK; ++t) {
+      // behind B_t: the slot of stage t - 2 (last read before B_{t-1}) takes stage t + 2
+      if (t + 2 < NK) { issue_stage(t + 2); wait_one_in_flight(); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // B_{t+1}: stage t + 1 has landed
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ consumer waves
+    const int px = lane & 15, g = lane >> 4;
+    {  // this wave's share of the halo tile: 10 x 18 records, piece q of the [row][pixel][16-byte vector] list goes to wave q % 4
+      constexpr int vpp = REC / 16, row_vecs = 18 * vpp, total = 10 * row_vecs;
+      const int y0 = ty * 8 - 1, x0 = tx * 16 - 1;
+      const char* origin = a.src + (((long long)n * a.H + y0) * a.W + x0) * (long long)REC;
+      const int rowstep = a.W * REC;
+      const int nq = a.halo_bytes >> 10;
+      for (int q = wave; q < nq; q += 4) {
+        const int L = q * 64 + lane;
+        const int r = L / row_vecs, rem = L - r * row_vecs;
+        const int p = rem / vpp, v = rem - p * vpp;
+        const bool ok = (L < total) & ((unsigned)(y0 + r) < (unsigned)a.H) & ((unsigned)(x0 + p) < (unsigned)a.W);
+        const long long off = ok ? (long long)(r * rowstep + p * REC + v * 16) : (reinterpret_cast<const char*>(&g_q8_zero16) - origin);
+        // (an asm statement, M0 saved and restored: with the builtin hipcc puts a full wait in front of every later ds_read of this wave)
+        unsigned keep;
+        const char* gp = origin + off;
+        const unsigned ldst = (unsigned)(uintptr_t)LDS_PTR(halo + q * 1024);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B_0
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[NCT][2];
+    i32x8 wf[NCT], x[2][2];
+    int sx[2][2];
+    int sw[(NCT + 3) / 4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + ct * 16 + g * 4);
+      acc[ct][0] = bv;
+      acc[ct][1] = bv;
+    }
+#pragma unroll
+    for (int q = 0; q < (NCT + 3) / 4; ++q) {  // weight scales of this lane's output channel in tiles 4q .. 4q+3, one byte each
+      int v = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < NCT) v |= (int)lwsc[(4 * q + e) * 16 + px] << (8 * e);
+      sw[q] = v;
+    }
+    const char* xpix = halo + ((2 * wave) * 18 + px) * REC;  // this lane's pixel in tile row 2w (halo coordinates: tap (0,0))
+    const int half = 16 * (g & 1);
+    auto rd_x = [&](int ks, i32x8 (&xv)[2], int (&sv)[2]) {
+      // data: 16 bytes of slot g >> 1 and 16 bytes of slot 2 + (g >> 1); scale: the byte of slot g
+      const int o0 = ((g >> 1) ? q_tap_pix<NCH>(4 * ks + 1) * REC + q_chunk<NCH>(4 * ks + 1) * 32 : q_tap_pix<NCH>(4 * ks + 0) * REC + q_chunk<NCH>(4 * ks + 0) * 32) + half;
+      const int o1 = ((g >> 1) ? q_tap_pix<NCH>(4 * ks + 3) * REC + q_chunk<NCH>(4 * ks + 3) * 32 : q_tap_pix<NCH>(4 * ks + 2) * REC + q_chunk<NCH>(4 * ks + 2) * 32) + half;
+      const int sA = (g & 1) ? q_tap_pix<NCH>(4 * ks + 1) * REC + q_chunk<NCH>(4 * ks + 1) : q_tap_pix<NCH>(4 * ks + 0) * REC + q_chunk<NCH>(4 * ks + 0);
+      const int sB = (g & 1) ? q_tap_pix<NCH>(4 * ks + 3) * REC + q_chunk<NCH>(4 * ks + 3) : q_tap_pix<NCH>(4 * ks + 2) * REC + q_chunk<NCH>(4 * ks + 2);
+      const int os = ((g >> 1) ? sB : sA) + DBI;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const char* p = xpix + r * 18 * REC;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(p + o0), hi = *reinterpret_cast<const i32x4*>(p + o1);
+        xv[r] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        sv[r] = (int)*reinterpret_cast<const unsigned char*>(p + os);
+      }
+    };
+    auto rd_w = [&](int slot, int ct) {
+      const char* p = ring + slot * KSB + (g * COB + ct * 16 + px) * 16;
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(p), hi = *reinterpret_cast<const i32x4*>(p + 4 * COB * 16);
+      wf[ct] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    rd_x(0, x[0], sx[0]);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) rd_w(0, ct);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      __builtin_amdgcn_s_barrier();  // B_{ks+1}: the weights of k-step ks + 1 are in their slot
+      asm volatile("" ::: "memory");
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < NK) rd_x(ks + 1, x[nxt], sx[nxt]);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        // (opsel picks the tile's byte of the packed weight scales; it must be an immediate: ct is a constant after unrolling)
+        switch (ct & 3) {
+          case 0:
+            acc[ct][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][0], acc[ct][0], 0, 0, 0, sw[ct >> 2], 0, sx[cur][0]);
+            acc[ct][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][1], acc[ct][1], 0, 0, 0, sw[ct >> 2], 0, sx[cur][1]);
+            break;
+          case 1:
+            acc[ct][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][0], acc[ct][0], 0, 0, 1, sw[ct >> 2], 0, sx[cur][0]);
+            acc[ct][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][1], acc[ct][1], 0, 0, 1, sw[ct >> 2], 0, sx[cur][1]);
+            break;
+          case 2:
+            acc[ct][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][0], acc[ct][0], 0, 0, 2, sw[ct >> 2], 0, sx[cur][0]);
+            acc[ct][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][1], acc[ct][1], 0, 0, 2, sw[ct >> 2], 0, sx[cur][1]);
+            break;
+          default:
+            acc[ct][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][0], acc[ct][0], 0, 0, 3, sw[ct >> 2], 0, sx[cur][0]);
+            acc[ct][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ct], x[cur][1], acc[ct][1], 0, 0, 3, sw[ct >> 2], 0, sx[cur][1]);
+            break;
+        }
+        if (ks + 1 < NK) rd_w((ks + 1) & 3, ct);  // this tile's fragment of the NEXT k-step, into the registers its MFMAs have just read
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // P: every wave has finished its LDS reads; the patch may overwrite halo and ring
+    asm volatile("" ::: "memory");
+    char* prow = smem + ((2 * wave) * 16 + px) * G::PSTR + g * 16;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      *reinterpret_cast<f32x4*>(prow + ct * 64) = acc[ct][0];
+      *reinterpret_cast<f32x4*>(prow + 16 * G::PSTR + ct * 64) = acc[ct][1];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+  if (wave >= 4) __builtin_amdgcn_s_barrier();  // P (loader side)
+  __builtin_amdgcn_s_barrier();  // F: the patch is complete
+  asm volatile("" ::: "memory");
+
+  // ---- items (pixel, 32 output channels) -> bf16 rows and / or Q8 records, all seven waves
+#pragma unroll 1
+  for (int it = 0; it < G::NIT; ++it) {
+    const int j = it * G::THREADS + tid;
+    if (j >= G::NITEM) break;
+    const int pxl = j / G::NOC, oc = j - pxl * G::NOC;
+    const int row = pxl >> 4, col = pxl & 15;
+    if (ty * 8 + row >= a.H || tx * 16 + col >= a.W) continue;
+    const int c0 = oc * 32;
+    const int nv = (a.Cout - c0 >= 32) ? 4 : (a.Cout - c0 + 7) / 8;  // 8-channel vectors of this block (Cout % 8 == 0)
+    const long long opix = tile_pix + (long long)row * a.W + col;
+    float v[32];
+    const char* pp = smem + pxl * G::PSTR + c0 * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 t = q < 2 * nv ? *reinterpret_cast<const f32x4*>(pp + q * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+    if (a.act == VMG_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (a.act == VMG_ACT_LRELU) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+    }
+    if (a.alpha != 1.0f) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] *= a.alpha;
+    }
+    if (a.res) {
+      const bf16* rp = a.res + opix * a.res_ps + c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < nv) {
+          const bf16x8 u = *reinterpret_cast<const bf16x8*>(rp + q * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)u[e];
+        }
+      }
+    }
+    if (a.out) {
+      bf16* op = a.out + opix * a.out_ps + c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < nv) {
+          bf16x8 tq;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tq[e] = (bf16)v[8 * q + e];
+          *reinterpret_cast<bf16x8*>(op + q * 8) = tq;
+        }
+      }
+    }
+    if (a.outq) {
+      // the record of the NEXT convolution is quantised from the bf16-ROUNDED values when a bf16 output exists too (both consumers then see the
+      // same tensor up to fp8 rounding); block scale: the power of two that maps the largest magnitude into (224, 448]
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        if (a.out) v[e] = (float)(bf16)v[e];
+        amax = fmaxf(amax, fabsf(v[e]));
+      }
+      const unsigned bits = __float_as_uint(amax);
+      int sb = (int)((bits >> 23) & 255) - 8 + ((bits & 0x7FFFFF) > 0x600000 ? 1 : 0);
+      sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+      const float mult = __uint_as_float((unsigned)(254 - sb) << 23);  // 2^(127 - sb)
+      int w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        int t = 0;
+        t = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * mult, v[4 * q + 1] * mult, t, false);
+        t = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * mult, v[4 * q + 3] * mult, t, true);
+        w8[q] = t;
+      }
+      char* qp = a.outq + opix * (long long)G::REC_OUT;
+      *reinterpret_cast<i32x4*>(qp + c0) = i32x4{w8[0], w8[1], w8[2], w8[3]};
+      *reinterpret_cast<i32x4*>(qp + c0 + 16) = i32x4{w8[4], w8[5], w8[6], w8[7]};  // (beyond Cout: zeros -- v was zero there)
+      qp[G::DBO + oc] = (char)sb;
+      if (oc == 0) {  // the rest of the 16 scale bytes: zero
+#pragma unroll
+        for (int e = G::NOC; e < 16; ++e) qp[G::DBO + e] = 0;
+      }
+    }
+  }
+}
+
+// ---- bf16 -> Q8 records (the first tensor of a chain; tests)
+__global__ __launch_bounds__(256) void q8_quantize_kernel(const bf16* __restrict__ x, long long x_ps, char* __restrict__ out, long long M, int C, int rec) {
+  const int nblk = (C + 31) / 32;
+  const long long total = M * nblk;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i / nblk;
+    const int b = (int)(i - pix * nblk), c0 = b * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c0 + 8 * q < C) {
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(x + pix * x_ps + c0 + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[8 * q + e] = (float)u[e]; amax = fmaxf(amax, fabsf(v[8 * q + e])); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[8 * q + e] = 0.f;
+      }
+    }
+    const unsigned bits = __float_as_uint(amax);
+    int sb = (int)((bits >> 23) & 255) - 8 + ((bits & 0x7FFFFF) > 0x600000 ? 1 : 0);
+    sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+    const float mult = __uint_as_float((unsigned)(254 - sb) << 23);
+    int w8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int t = 0;
+      t = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * mult, v[4 * q + 1] * mult, t, false);
+      t = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * mult, v[4 * q + 3] * mult, t, true);
+      w8[q] = t;
+    }
+    char* qp = out + pix * (long long)rec;
+    *reinterpret_cast<i32x4*>(qp + c0) = i32x4{w8[0], w8[1], w8[2], w8[3]};
+    *reinterpret_cast<i32x4*>(qp + c0 + 16) = i32x4{w8[4], w8[5], w8[6], w8[7]};
+    qp[nblk * 32 + b] = (char)sb;
+    if (b == 0)
+      for (int e = nblk; e < 16; ++e) qp[nblk * 32 + e] = 0;
+  }
+}
+
+// ---- weight pack: per-output-channel E8M0 scale, then the k-step images
+struct PackQ {
+  const float* w;  // (O, I, 3, 3)
+  char* out;
+  int O, I, transpose_flip, cob, nch, nk;
+};
+__device__ __forceinline__ float packq_w(const PackQ& p, int oc, int kc, int tap) {
+  // forward: out channel oc, in channel kc; data gradient: out "channel" = input channel oc of w, K = output channels, taps mirrored
+  return p.transpose_flip ? p.w[((long long)kc * p.I + oc) * 9 + (8 - tap)] : p.w[((long long)oc * p.I + kc) * 9 + tap];
+}
+__global__ __launch_bounds__(256) void convq8_scale_kernel(const PackQ p) {  // one block per output channel
+  __shared__ float sm[4];
+  const int oc = blockIdx.x;
+  const int on = p.transpose_flip ? p.I : p.O, kn = p.transpose_flip ? p.O : p.I;
+  float m = 0.f;
+  if (oc < on)
+    for (int i = threadIdx.x; i < kn * 9; i += 256) m = fmaxf(m, fabsf(packq_w(p, oc, i / 9, i % 9)));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const unsigned bits = __float_as_uint(m);
+    int sb = (int)((bits >> 23) & 255) - 8 + ((bits & 0x7FFFFF) > 0x600000 ? 1 : 0);
+    sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+    reinterpret_cast<unsigned char*>(p.out + (long long)p.nk * p.cob * 128)[oc] = (unsigned char)sb;
+  }
+}
+__global__ __launch_bounds__(256) void convq8_pack_kernel(const PackQ p) {
+  // one thread per 4 bytes of the image: index = ((ks * 2 + h) * 4 + g) * cob * 4 + co * 4 + q   (q: which 4 of the 16 bytes)
+  const long long total = (long long)p.nk * 8 * p.cob * 4;
+  const int on = p.transpose_flip ? p.I : p.O, kn = p.transpose_flip ? p.O : p.I;
+  const unsigned char* sc = reinterpret_cast<const unsigned char*>(p.out + (long long)p.nk * p.cob * 128);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i & 3);
+    long long t = i >> 2;
+    const int co = (int)(t % p.cob); t /= p.cob;
+    const int g = (int)(t & 3); t >>= 2;
+    const int h = (int)(t & 1);
+    const int ks = (int)(t >> 1);
+    const int s = 4 * ks + 2 * h + (g >> 1);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s < 9 * p.nch && co < on) {
+      const int tap = s / p.nch, chunk = s % p.nch;
+      const float mult = __uint_as_float((unsigned)(254 - sc[co]) << 23);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kc = chunk * 32 + 16 * (g & 1) + 4 * q + e;
+        if (kc < kn) v[e] = packq_w(p, co, kc, tap) * mult;
+      }
+    }
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    reinterpret_cast<int*>(p.out)[i] = w;
+  }
+}
+
+template <int NCT, int NCH>
+int launch_q8(const ConvQ& k, hipStream_t st) {
+  using G = QGeo<NCT, NCH>;
+  ConvQ kk = k;
+  kk.halo_bytes = (10 * 18 * G::REC + 1023) & ~1023;
+  int lds = kk.halo_bytes + 4 * G::KSB + G::COB * 4 + ((G::COB + 15) & ~15);
+  const int patch = 128 * G::PSTR;
+  if (lds < patch) lds = patch;
+  VMG_CHECK(lds <= 160 * 1024, "conv_q8: LDS request %d B exceeds 160 KiB", lds);
+  auto fn = convq8_kernel<NCT, NCH>;
+  static bool attr_set[VMG_MAX_DEVICES] = {};
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = true;
+  }
+  const long long nblk = (long long)k.N * k.tiles_y * k.tiles_x;
+  VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv_q8: bad grid %lld", nblk);
+  const bool prof = vmg_prof_before(VMG_PROF_CONV3X3, (long long)k.N * k.H * k.W, st);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(G::THREADS), lds, st, kk);
+  if (prof) vmg_prof_after(st);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmg_q8_record_bytes(int C) { return C > 0 ? (C + 31) / 32 * 32 + 16 : -1; }
+
+extern "C" int vmg_q8_quantize(const void* x, int64_t x_ps, void* out, int64_t M, int C, void* stream) {
+  VMG_CHECK(x && out && M > 0 && C > 0 && C % 8 == 0 && C <= 512 && x_ps >= C && x_ps % 8 == 0, "q8_quantize: bad arguments (C a multiple of 8, <= 512)");
+  VMG_CHECK(((uintptr_t)x | (uintptr_t)out) % 16 == 0, "q8_quantize: pointers must be 16-byte aligned");
+  const long long total = M * ((C + 31) / 32);
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  hipLaunchKernelGGL(q8_quantize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (long long)x_ps, (char*)out, (long long)M, C,
+                     vmg_q8_record_bytes(C));
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int q8_shape(int Cout, int Cin, int* nct, int* nch) {
+  VMG_CHECK(Cout == Cin && (Cout == 144 || Cout == 112), "conv_q8: instantiated for 144 -> 144 and 112 -> 112 channels (got %d -> %d)", Cin, Cout);
+  *nct = Cout / 16;
+  *nch = (Cin + 31) / 32;
+  return 0;
+}
+
+extern "C" int64_t vmg_convq8_pack_bytes(int Cout, int Cin) {
+  int nct, nch;
+  if (q8_shape(Cout, Cin, &nct, &nch)) return -1;
+  const int nk = (9 * nch + 3) / 4;
+  return (int64_t)nk * nct * 16 * 128 + ((nct * 16 + 15) & ~15);
+}
+
+extern "C" int vmg_convq8_pack(const float* w, int O, int I, int transpose_flip, void* packed, void* stream) {
+  VMG_CHECK(w && packed, "convq8_pack: null pointer");
+  int nct, nch;
+  if (q8_shape(transpose_flip ? I : O, transpose_flip ? O : I, &nct, &nch)) return -1;
+  PackQ p;
+  p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.transpose_flip = transpose_flip; p.cob = nct * 16; p.nch = nch; p.nk = (9 * nch + 3) / 4;
+  hipLaunchKernelGGL(convq8_scale_kernel, dim3(p.cob), dim3(256), 0, (hipStream_t)stream, p);
+  VMG_LAUNCH_CHECK();
+  const long long total = (long long)p.nk * 8 * p.cob * 4;
+  hipLaunchKernelGGL(convq8_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_convq8_fwd(const vmg_convq8_desc* d, void* stream) {
+  VMG_CHECK(d && d->src && d->packed && (d->out || d->outq), "convq8_fwd: null source / weights / no output");
+  VMG_CHECK(d->N > 0 && d->H > 0 && d->W > 0, "convq8_fwd: bad shape");
+  int nct, nch;
+  if (q8_shape(d->Cout, d->Cin, &nct, &nch)) return -1;
+  VMG_CHECK(d->act == VMG_ACT_NONE || d->act == VMG_ACT_RELU || d->act == VMG_ACT_LRELU, "convq8_fwd: activation none / relu / lrelu");
+  VMG_CHECK(!(d->res && d->act != VMG_ACT_NONE), "convq8_fwd: activation + residual in one epilogue is not supported");
+  VMG_CHECK(((uintptr_t)d->src | (uintptr_t)d->packed | (uintptr_t)d->out | (uintptr_t)d->outq | (uintptr_t)d->res) % 16 == 0, "convq8_fwd: pointers must be 16-byte aligned");
+  VMG_CHECK((!d->out || (d->out_ps >= d->Cout && d->out_ps % 8 == 0)) && (!d->res || (d->res_ps >= d->Cout && d->res_ps % 8 == 0)),
+            "convq8_fwd: bf16 rows must be 16-byte granular");
+  ConvQ k;
+  memset(&k, 0, sizeof(k));
+  k.src = (const char*)d->src; k.wpack = (const char*)d->packed; k.bias = d->bias;
+  k.out = (bf16*)d->out; k.out_ps = d->out_ps; k.outq = (char*)d->outq; k.res = (const bf16*)d->res; k.res_ps = d->res_ps;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.Cout = d->Cout; k.tiles_x = cdiv(d->W, 16); k.tiles_y = cdiv(d->H, 8);
+  k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+  hipStream_t st = (hipStream_t)stream;
+  return nct == 9 ? launch_q8<9, 5>(k, st) : launch_q8<7, 4>(k, st);
+}

@@ -653,6 +653,52 @@ def grouped_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return _GroupedConv2d.apply(x, weight, bias, (int(groups), int(ks), int(act), float(slope), int(N), int(H), int(W)))
 
 
+# ---- fp8 chains: conv1 / conv2 of every residual block on the block-scaled fp8 kernel (csrc/conv_fp8.hip) ----------------------
+FP8_CHAINS = False          # process-wide default (set_fp8_chains); VMG(fp8_chains=True) switches it on per model
+FP8_STATS = {"chains": 0}   # forward chains that ran on the fp8 kernel (tests)
+_Q8_CACHE = {}
+
+
+def set_fp8_chains(on: bool):
+    global FP8_CHAINS
+    FP8_CHAINS = bool(on)
+
+
+def packed_q8(weight: torch.Tensor) -> K.PackedQ8:
+    """The fp8 weight image of a 3x3 convolution, cached per parameter version / optimizer epoch (rebuilt on demand: two small launches)."""
+    ver = (weight._version, _WEIGHT_EPOCH[0])
+    hit = _Q8_CACHE.get(id(weight))
+    if hit is not None and hit[0] == ver and hit[2] is weight:
+        return hit[1]
+    pw = K.pack_conv_weight_q8(weight.detach().contiguous())
+    _Q8_CACHE[id(weight)] = (ver, pw, weight)
+    return pw
+
+
+def _chain_forward_fp8(srcs, params, r_scaling, keep_t: bool):
+    """ResidualBlocksWithInputConv forward with the 2 * nblk block convolutions in fp8: y_0 = lrelu(conv0(srcs)) on the bf16 kernel, quantised to
+    records once; then per block  t_k = relu(conv1(q(y_k)))  and  y_{k+1} = y_k + r * conv2(q(t_k))  on vmg_convq8_fwd -- every convolution
+    writes the records its successor reads, the skip path stays bf16.  keep_t: also write t_k as bf16 (the backward needs it)."""
+    nblk = (len(params) - 2) // 4
+    N, H, W = srcs[0].shape[0], srcs[0].shape[1], srcs[0].shape[2]
+    dt, M = srcs[0].dtype, srcs[0].shape[0] * srcs[0].shape[1] * srcs[0].shape[2]
+    src_ch = [t.shape[-1] for t in srcs]
+    w0, b0 = params[0], params[1]
+    C = w0.shape[0]
+    t0_, m0_, d0_ = choose_tiling(M, C, 3, dt, src_ch)
+    y0, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=m0_, deep=d0_)
+    ys, ts = [y0], []
+    q = K.q8_quantize(y0) if nblk else None
+    for k in range(nblk):
+        w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
+        t, tq = K.conv_q8_forward(q, packed_q8(w1), b1, N, H, W, act=hip.ACT_RELU, want_bf16=keep_t, want_q8=True)
+        y, q = K.conv_q8_forward(tq, packed_q8(w2), b2, N, H, W, alpha=r_scaling, res=ys[k], want_bf16=True, want_q8=k + 1 < nblk)
+        ts.append(t)
+        ys.append(y)
+    FP8_STATS["chains"] += 1
+    return ys, ts
+
+
 class _ResidualChain(_Fn):
     """ResidualBlocksWithInputConv (models/trajectory.py:16-52, 165-221) as ONE autograd node:
         y0 = lrelu_0.1(conv0(cat(srcs)));  y_{k+1} = y_k + r * conv2_k(relu(conv1_k(y_k)))
@@ -679,7 +725,7 @@ class _ResidualChain(_Fn):
                                         own_output=own_output)
 
     @staticmethod
-    def forward(ctx, r_scaling, nsrc, *args):
+    def forward(ctx, r_scaling, nsrc, fp8, *args):
         recompute = nsrc < 0  # (encoded in the sign: activation recompute -- keep the sources only, run the chain again in the backward)
         nsrc = abs(nsrc)
         srcs = list(args[:nsrc])
@@ -691,16 +737,21 @@ class _ResidualChain(_Fn):
         src_ch = [t.shape[-1] for t in srcs]
         w0, b0 = params[0], params[1]
         C = w0.shape[0]
-        t0_, _, d0_ = choose_tiling(M, C, 3, dt, src_ch)
-        tiles, _, deep = choose_tiling(M, C, 3, dt, [C])
-        pw1 = [packed(params[2 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
-        pw2 = [packed(params[4 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
-        ys, ts = K.resblock_chain_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, 0.1, d0_, pw1,
-                                          [params[3 + 4 * k] for k in range(nblk)], pw2, [params[5 + 4 * k] for k in range(nblk)], r_scaling, deep,
-                                          own_output=recompute)
+        fp8 = bool(fp8) and dt == torch.bfloat16 and nblk > 0 and K.q8_eligible(C, C)
+        ctx.fp8 = fp8
+        if fp8:
+            ys, ts = _chain_forward_fp8(srcs, params, r_scaling, keep_t=any(ctx.needs_input_grad) and not recompute)
+        else:
+            t0_, _, d0_ = choose_tiling(M, C, 3, dt, src_ch)
+            tiles, _, deep = choose_tiling(M, C, 3, dt, [C])
+            pw1 = [packed(params[2 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
+            pw2 = [packed(params[4 + 4 * k], dt, "fwd", [C], tiles=tiles, deep=deep) for k in range(nblk)]
+            ys, ts = K.resblock_chain_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, 0.1, d0_, pw1,
+                                              [params[3 + 4 * k] for k in range(nblk)], pw2, [params[5 + 4 * k] for k in range(nblk)], r_scaling, deep,
+                                              own_output=recompute)
         ctx.recompute = recompute
         ctx.meta = (r_scaling, nsrc, nblk, N, H, W, src_ch, C)
-        ctx.wgrad = any(ctx.needs_input_grad[2 + nsrc:])
+        ctx.wgrad = any(ctx.needs_input_grad[3 + nsrc:])
         ctx.defer = ctx.wgrad and DEFERRED.mode == "deferred"
         if ctx.defer:
             for p, pb in zip(params[0::2], params[1::2]):
@@ -718,7 +769,8 @@ class _ResidualChain(_Fn):
         params = ctx.params
         srcs = list(ctx.saved_tensors[:nsrc])
         if ctx.recompute:
-            ys, ts = _ResidualChain._run(srcs, params, r, False)  # the forward once more: +1/3 of the chain's FLOPs, -31 saved tensors per call
+            # the forward once more: +1/3 of the chain's FLOPs, -31 saved tensors per call
+            ys, ts = _chain_forward_fp8(srcs, params, r, True) if ctx.fp8 else _ResidualChain._run(srcs, params, r, False)
             ys = ys[:max(nblk, 1)]
         else:
             ys = list(ctx.saved_tensors[nsrc:nsrc + max(nblk, 1)])  # y_0 .. y_{nblk-1}
@@ -747,7 +799,7 @@ class _ResidualChain(_Fn):
         d_srcs = []
         off = 0
         for i, c in enumerate(src_ch):
-            if ctx.needs_input_grad[2 + i]:
+            if ctx.needs_input_grad[3 + i]:
                 t_, m_, d_ = choose_tiling(M, c, 3, dt, [C])
                 dx, _ = K.conv_forward([dpre0], packed(w0, dt, "dgrad", None, off, c, tiles=t_, deep=d_), None, N, H, W, mt=m_, deep=d_)
                 d_srcs.append(dx)
@@ -761,19 +813,20 @@ class _ResidualChain(_Fn):
                 DEFERRED.drain()
         elif ctx.wgrad:
             pg[0], pg[1] = _wgrad_now(w0, True, srcs, src_ch, dpre0, 3, N, H, W)
-        return (None, None, *d_srcs, *pg)
+        return (None, None, None, *d_srcs, *pg)
 
 
-def residual_chain(srcs: Sequence[torch.Tensor], conv0, blocks, r_scaling: float, recompute: bool = False) -> torch.Tensor:
+def residual_chain(srcs: Sequence[torch.Tensor], conv0, blocks, r_scaling: float, recompute: bool = False, fp8: bool = False) -> torch.Tensor:
     """srcs: channels-last (n,h,w,c_s) tensors (virtual concat); conv0 and blocks[k].conv1/.conv2 are nn.Conv2d holders.
-    recompute: keep only the sources for the backward and run the chain again there (activation recompute)."""
+    recompute: keep only the sources for the backward and run the chain again there (activation recompute).
+    fp8 (or functional.set_fp8_chains(True)): the block convolutions of the FORWARD run on the fp8 kernel (bf16 tensors, 144 / 112 channels)."""
     params = [conv0.weight, conv0.bias]
     for b in blocks:
         params += [b.conv1.weight, b.conv1.bias, b.conv2.weight, b.conv2.bias]
     ok = all(isinstance(p, torch.nn.Parameter) for p in params) and all(t.is_contiguous() and t.shape[-1] % 8 == 0 for t in srcs)
     if not ok:
         raise HipError("residual_chain needs contiguous sources with multiples of 8 channels and nn.Parameter weights")
-    return _ResidualChain.apply(float(r_scaling), -len(srcs) if recompute else len(srcs), *srcs, *params)
+    return _ResidualChain.apply(float(r_scaling), -len(srcs) if recompute else len(srcs), bool(fp8 or FP8_CHAINS), *srcs, *params)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = hip.ACT_NONE, alpha: float = 1.0,

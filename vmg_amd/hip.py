@@ -49,6 +49,17 @@ class ChainDesc(ctypes.Structure):
     ]
 
 
+class ConvQ8Desc(ctypes.Structure):
+    """vmg_convq8_desc (include/vmg_hip.h)."""
+    _fields_ = [
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
+        ("src", c_void_p), ("packed", c_void_p), ("bias", c_void_p),
+        ("out", c_void_p), ("out_ps", c_int64), ("outq", c_void_p),
+        ("res", c_void_p), ("res_ps", c_int64),
+        ("act", c_int), ("slope", c_float), ("alpha", c_float),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol of include/vmg_hip.h must be listed (tests/test_abi.py checks)
@@ -116,6 +127,11 @@ SIGNATURES = {
     "vmg_charbonnier_edge_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "vmg_charbonnier_edge_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     "vmg_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_void_p]),
+    "vmg_q8_record_bytes": (c_int, [c_int]),
+    "vmg_q8_quantize": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "vmg_convq8_pack_bytes": (c_int64, [c_int, c_int]),
+    "vmg_convq8_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vmg_convq8_fwd": (c_int, [POINTER(ConvQ8Desc), c_void_p]),
     "vmg_grad_clip_ws_bytes": (c_int64, []),
     "vmg_grad_clip_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vmg_tile_accumulate": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -942,3 +942,86 @@ class PackPlan:
             self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(packs[0].buf.device)
             self.sig, self.n, self.blocks = sig, len(packs), blk
         hip.check(l.vmg_pack_run(self.dev.data_ptr(), self.n, self.blocks, hip.stream_ptr()), "vmg_pack_run")
+
+
+# ---- fp8 (e4m3, block-scaled) convolution: Q8 records, packed weights, the kernel (csrc/conv_fp8.hip) ------------------------------------
+def q8_record_bytes(C: int) -> int:
+    return (C + 31) // 32 * 32 + 16
+
+
+def q8_quantize(x: torch.Tensor) -> torch.Tensor:
+    """bf16 channels-last (..., C) -> Q8 records uint8 (..., q8_record_bytes(C)) (vmg_q8_quantize)."""
+    hip.require_cuda(x)
+    C = x.shape[-1]
+    if x.dtype != torch.bfloat16 or x.stride(-1) != 1:
+        raise HipError("q8_quantize: bf16 channels-last tensor expected")
+    ps = _pix_stride(x)
+    M = x.numel() // C
+    out = torch.empty(tuple(x.shape[:-1]) + (q8_record_bytes(C),), dtype=torch.uint8, device=x.device)
+    hip.check(hip.lib().vmg_q8_quantize(x.data_ptr(), ps, out.data_ptr(), M, C, hip.stream_ptr()), "vmg_q8_quantize")
+    return out
+
+
+def q8_dequantize(rec: torch.Tensor, C: int) -> torch.Tensor:
+    """Records -> fp32 (..., C) with torch ops (tests and tools; the product path never dequantises)."""
+    nb = (C + 31) // 32
+    data = rec[..., :nb * 32].contiguous().view(torch.float8_e4m3fn).float().reshape(*rec.shape[:-1], nb, 32)
+    scale = torch.exp2(rec[..., nb * 32:nb * 32 + nb].float() - 127.0)
+    return (data * scale[..., None]).reshape(*rec.shape[:-1], nb * 32)[..., :C]
+
+
+class PackedQ8:
+    __slots__ = ("buf", "cout", "cin", "call")
+
+    def __init__(self, buf, cout, cin, call):
+        self.buf, self.cout, self.cin, self.call = buf, cout, cin, call
+
+
+def pack_conv_weight_q8(w: torch.Tensor, transpose_flip: bool = False) -> PackedQ8:
+    """fp32 (O, I, 3, 3) -> the fp8 convolution's weight image (vmg_convq8_pack): e4m3 with one power-of-two scale per output channel."""
+    hip.require_cuda(w)
+    if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        raise HipError("pack_conv_weight_q8 expects a contiguous fp32 (O, I, 3, 3) weight")
+    O, I = w.shape[0], w.shape[1]
+    cout, cin = (I, O) if transpose_flip else (O, I)
+    nbytes = hip.lib().vmg_convq8_pack_bytes(cout, cin)
+    if nbytes <= 0:
+        raise HipError(f"vmg_convq8_pack_bytes: {hip.lib().vmg_last_error().decode()}")
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=w.device)
+    hip.check(hip.lib().vmg_convq8_pack(w.data_ptr(), O, I, 1 if transpose_flip else 0, buf.data_ptr(), hip.stream_ptr()), "vmg_convq8_pack")
+    return PackedQ8(buf, cout, cin, (w.data_ptr(), O, I, 1 if transpose_flip else 0))
+
+
+def q8_eligible(cout: int, cin: int) -> bool:
+    return cout == cin and cout in (144, 112)
+
+
+_Q8_DESC = hip.ConvQ8Desc()
+
+
+def conv_q8_forward(src: torch.Tensor, pw: PackedQ8, bias: Optional[torch.Tensor], N: int, H: int, W: int, act: int = hip.ACT_NONE,
+                    slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None, want_bf16: bool = True, want_q8: bool = True,
+                    out: Optional[torch.Tensor] = None):
+    """[res +] alpha * act(conv3x3(src records) + bias) -> (bf16 (N,H,W,Cout) or None, records (N,H,W,rec) or None) (vmg_convq8_fwd)."""
+    hip.require_cuda(src, bias, res, out)
+    rec_in = q8_record_bytes(pw.cin)
+    if src.dtype != torch.uint8 or not src.is_contiguous() or src.shape[-1] != rec_in or src.numel() != N * H * W * rec_in:
+        raise HipError(f"conv_q8: contiguous uint8 records (N*H*W, {rec_in}) expected, got {tuple(src.shape)}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != pw.cout or not bias.is_contiguous()):
+        raise HipError("conv_q8: bias must be contiguous fp32 of length Cout")
+    if res is not None and (res.dtype != torch.bfloat16 or res.shape[-1] != pw.cout or res.numel() // pw.cout != N * H * W):
+        raise HipError("conv_q8: the residual must be a bf16 tensor of the output's shape")
+    o = oq = None
+    if want_bf16:
+        o = out if out is not None else torch.empty((N, H, W, pw.cout), dtype=torch.bfloat16, device=src.device)
+    if want_q8:
+        oq = torch.empty((N, H, W, q8_record_bytes(pw.cout)), dtype=torch.uint8, device=src.device)
+    d = _Q8_DESC
+    d.N, d.H, d.W, d.Cin, d.Cout = N, H, W, pw.cin, pw.cout
+    d.src, d.packed, d.bias = src.data_ptr(), pw.buf.data_ptr(), bias.data_ptr() if bias is not None else None
+    d.out, d.out_ps = (o.data_ptr(), _pix_stride(o)) if o is not None else (None, 0)
+    d.outq = oq.data_ptr() if oq is not None else None
+    d.res, d.res_ps = (res.data_ptr(), _pix_stride(res)) if res is not None else (None, 0)
+    d.act, d.slope, d.alpha = act, slope, alpha
+    hip.check(hip.lib().vmg_convq8_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_convq8_fwd")
+    return o, oq

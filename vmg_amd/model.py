@@ -321,11 +321,12 @@ class ResidualBlocksWithInputConv(nn.Module):
         self.main = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1), nn.LeakyReLU(0.1),
                                   nn.Sequential(*[ResidualBlockNoBN0(out_channels, r_scaling) for _ in range(num_blocks)]))
         self.recompute = False  # VMG(recompute_chains=True): drop the 2 * num_blocks intermediates, rebuild them in the backward
+        self.fp8 = False        # VMG(fp8_chains=True): the block convolutions of the forward on the fp8 kernel
 
     def forward(self, srcs: Sequence[torch.Tensor]):
         blocks = list(self.main[2])
         r = blocks[0].res_scale if blocks else 1.0
-        return FH.residual_chain([t.contiguous() for t in srcs], self.main[0], blocks, r, recompute=self.recompute and torch.is_grad_enabled())
+        return FH.residual_chain([t.contiguous() for t in srcs], self.main[0], blocks, r, recompute=self.recompute and torch.is_grad_enabled(), fp8=self.fp8)
 
 
 class LTAM_multi_head(nn.Module):
@@ -596,7 +597,7 @@ class VMG(nn.Module):
                  non_linear=True, gating=True, symm=True, symm_act=nn.Tanh, relu_scale=True, relu_scale_norm=False,
                  ffn_type='vanilla', mixer_type=['mbconv', 'mbconv', 'mlps', 'mlps'], mixer_n=[2, 3, None, None], r_scaling=1.,
                  chunk_ratios=[1 / 4, 1 / 4, 3 / 16, 1 / 8], traj_mode='wins', twins=[2, 2], traj_scale=True, traj_refine=None,
-                 m_scaling=1., if_local_fuse=False, channel_mixer='vanilla', compute_dtype=torch.float32, recompute_chains=False):
+                 m_scaling=1., if_local_fuse=False, channel_mixer='vanilla', compute_dtype=torch.float32, recompute_chains=False, fp8_chains=False):
         super().__init__()
         # --- options the hand-written path implements (every self-consistent shipped config)
         if not (ltam and retention_decay and non_linear and gating and symm and relu_scale) or relu_scale_norm or if_concat:
@@ -619,6 +620,7 @@ class VMG(nn.Module):
         self.init_H, self.init_W = image_size
         self.compute_dtype = compute_dtype
         self.recompute_chains = bool(recompute_chains)  # the recurrent residual chains keep their inputs only and are re-run in the backward
+        self.fp8_chains = bool(fp8_chains)  # conv1 / conv2 of the chains' residual blocks in fp8 (e4m3, block-scaled; compute_dtype bf16, 144 / 112 channels)
         self.spynet = SPyNet(spynet_pretrained) if spynet_pretrained is not None else None
 
         enc_dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths[:self.num_enc_layers]))]
@@ -751,11 +753,11 @@ class VMG(nn.Module):
         if self.spynet is None:
             raise HipError("VMG.spynet is None: the trajectory modules need optical flow (the reference crashes here too, "
                            "models/trajectory.py:329); construct with spynet_pretrained or attach SPyNet(None)")
-        if getattr(self, "_recompute_applied", None) != self.recompute_chains:
+        if getattr(self, "_recompute_applied", None) != (self.recompute_chains, self.fp8_chains):
             for m in self.modules():
                 if isinstance(m, ResidualBlocksWithInputConv):
-                    m.recompute = self.recompute_chains
-            self._recompute_applied = self.recompute_chains
+                    m.recompute, m.fp8 = self.recompute_chains, self.fp8_chains
+            self._recompute_applied = (self.recompute_chains, self.fp8_chains)
         FH.DROP.begin(x.device, self.training)  # the DropPath masks of this pass in one draw (functional._DropPlan)
         # T1 (SURVEY trap): every MorphFC mixer multiplies its mlp_h / mlp_w weights by Gamma at each forward call -- all of them here, in one
         # launch, with their packs rebuilt in one more; each mixer then skips its own multiply for this call
