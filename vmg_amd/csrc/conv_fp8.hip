@@ -216,6 +216,17 @@ __global__ __launch_bounds__(448, 2) void convq8_kernel(const ConvQ a) {
         }
         if (ks + 1 < NK) rd_w((ks + 1) & 3, ct);  // this tile's fragment of the NEXT k-step, into the registers its MFMAs have just read
       }
+      // pin the order: two MFMAs, then up to three LDS reads -- the next k-step's activation fragments and scale bytes first (their registers
+      // are free), then each tile's fragment right behind the MFMAs that read its registers.  Left alone hipcc issues all 18 MFMAs and then
+      // all 24 reads, and the next k-step starts with the whole LDS latency exposed.
+      if (ks + 1 < NK) {
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_barrier();  // P: every wave has finished its LDS reads; the patch may overwrite halo and ring
     asm volatile("" ::: "memory");
@@ -232,10 +243,14 @@ __global__ __launch_bounds__(448, 2) void convq8_kernel(const ConvQ a) {
   asm volatile("" ::: "memory");
 
   // ---- items (pixel, 32 output channels) -> bf16 rows and / or Q8 records, all seven waves
+  unsigned char* lsc = reinterpret_cast<unsigned char*>(smem + 128 * G::PSTR);  // [128 pixels][16] block scales of the record output
+  // (the residual vectors are loaded inside the item: fetching them at kernel start -- the bf16 kernel's way -- was SLOWER here, 16.1 vs 15.5 us at
+  //  M = 32 768: the 9.4 MB then compete with the halo and the first weight stages for the first barrier, and this kernel's K loop is too short
+  //  to win it back; one item per iteration, not unrolled: 15.5 vs 16.3 us)
 #pragma unroll 1
   for (int it = 0; it < G::NIT; ++it) {
     const int j = it * G::THREADS + tid;
-    if (j >= G::NITEM) break;
+    if (j >= G::NITEM) continue;
     const int pxl = j / G::NOC, oc = j - pxl * G::NOC;
     const int row = pxl >> 4, col = pxl & 15;
     if (ty * 8 + row >= a.H || tx * 16 + col >= a.W) continue;
@@ -262,12 +277,14 @@ __global__ __launch_bounds__(448, 2) void convq8_kernel(const ConvQ a) {
     }
     if (a.res) {
       const bf16* rp = a.res + opix * a.res_ps + c0;
+      bf16x8 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const bf16x8*>(rp + (q < nv ? q * 8 : 0));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q < nv) {
-          const bf16x8 u = *reinterpret_cast<const bf16x8*>(rp + q * 8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)u[e];
+          for (int e = 0; e < 8; ++e) v[8 * q + e] += (float)u[q][e];
         }
       }
     }
@@ -307,10 +324,21 @@ __global__ __launch_bounds__(448, 2) void convq8_kernel(const ConvQ a) {
       char* qp = a.outq + opix * (long long)G::REC_OUT;
       *reinterpret_cast<i32x4*>(qp + c0) = i32x4{w8[0], w8[1], w8[2], w8[3]};
       *reinterpret_cast<i32x4*>(qp + c0 + 16) = i32x4{w8[4], w8[5], w8[6], w8[7]};  // (beyond Cout: zeros -- v was zero there)
-      qp[G::DBO + oc] = (char)sb;
-      if (oc == 0) {  // the rest of the 16 scale bytes: zero
+      lsc[pxl * 16 + oc] = (unsigned char)sb;  // (collected in LDS: one 16-byte store per pixel below instead of NOC byte stores)
+    }
+  }
+  if (a.outq) {
+    __syncthreads();
+    if (tid < 128) {
+      const int row = tid >> 4, col = tid & 15;
+      if (ty * 8 + row < a.H && tx * 16 + col < a.W) {
+        i32x4 sv = *reinterpret_cast<const i32x4*>(lsc + tid * 16);
+        // bytes NOC .. 15 of the scale vector are zero (the LDS bytes there were never written)
+        constexpr int full = G::NOC / 4, part = G::NOC % 4;
 #pragma unroll
-        for (int e = G::NOC; e < 16; ++e) qp[G::DBO + e] = 0;
+        for (int wd = 0; wd < 4; ++wd) sv[wd] = wd < full ? sv[wd] : (wd == full && part ? (sv[wd] & ((1 << (8 * part)) - 1)) : 0);
+        char* qp = a.outq + (tile_pix + (long long)row * a.W + col) * (long long)G::REC_OUT;
+        *reinterpret_cast<i32x4*>(qp + G::DBO) = sv;
       }
     }
   }
@@ -421,7 +449,7 @@ int launch_q8(const ConvQ& k, hipStream_t st) {
   ConvQ kk = k;
   kk.halo_bytes = (10 * 18 * G::REC + 1023) & ~1023;
   int lds = kk.halo_bytes + 4 * G::KSB + G::COB * 4 + ((G::COB + 15) & ~15);
-  const int patch = 128 * G::PSTR;
+  const int patch = 128 * G::PSTR + 128 * 16;  // the epilogue patch and, behind it, the block scales of the record output
   if (lds < patch) lds = patch;
   VMG_CHECK(lds <= 160 * 1024, "conv_q8: LDS request %d B exceeds 160 KiB", lds);
   auto fn = convq8_kernel<NCT, NCH>;
