@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, T, H, W = 4, 7, 64, 64
 FWD_GFLOP_PER_FRAME = 292.8  # Conv+Linear, measured on the reference (SURVEY section 6 / BASELINE.md section 2)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA), same guide
 # --workload: the default is the configuration BASELINE.json's metric is quoted on (configs[1]); the other two are the per-GPU
 # shards of configs[2] (full VMG-REDS, 8 clips over 8 GPUs = 1 clip per GPU) and configs[3] (sliding-window inference)
 WORKLOADS = {
@@ -36,6 +37,9 @@ WORKLOADS = {
     "train_vimeo": dict(cfg="few", batch=1, frames=7, size=(256, 448), ch=144,
                         name="VMG-few_levels train step on the Vimeo stress shape, per-GPU batch 1x7x3x256x448 -> 4x SR, bf16 weights "
                              "(BASELINE configs[4] without its fp8 weights: not built)"),
+    "train_swin": dict(cfg="few", batch=4, frames=7, size=64, ch=144, swin=True,
+                       name="VMG-REDS-few_levels with temporal_empty = false (3-D shifted-window attention on stage 1, models/swin_3d.py; no shipped config "
+                            "enables it, SURVEY T8), train step, per-GPU batch 4x7x3x64x64 -> 4x SR"),
     "infer": dict(cfg="few", batch=1, frames=100, size=128, ch=144,
                   name="VMG-REDS-few_levels sliding-window inference, 100 x 180x320 -> 720x1280, windows 50/25, tiles 128/20 (BASELINE configs[3])"),
 }
@@ -51,28 +55,46 @@ def build_model(device, wl=None):
     torch.manual_seed(0)
     infer = wl["frames"] > 50
     hw = list(wl["size"]) if isinstance(wl["size"], tuple) else [wl["size"]] * 2
+    net = dict(REDS_FULL if wl["cfg"] == "full" else REDS_FEW_LEVELS)
+    if wl.get("swin"):
+        net["temporal_empty"] = False
     m = vmg_amd.VMG(num_frames=50 if infer else wl["frames"], image_size=hw, is_train=not infer, spynet_pretrained=None,
-                    compute_dtype=torch.bfloat16, **(REDS_FULL if wl["cfg"] == "full" else REDS_FEW_LEVELS))
+                    compute_dtype=torch.bfloat16, **net)
     m.spynet = vmg_amd.SPyNet(None)  # the configs' SPyNet checkpoint is a download URL: random init, as stated in "data"
     m = m.to(device)
     return m.eval() if infer else m.train()
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle (CPU restatement, fp32, all host cores): forward + loss + backward + AdamW.  Two legs: a short warm-up pass on
-    1 clip x 5 frames (thread pool start, reported on stderr only) and then ONE step of the bench's own job -- 4 clips x 7
-    frames x 64 x 64, the same batch shape as the GPU number, AdamW over every parameter included."""
+def cpu_baseline(workload="train"):
+    """The oracle (CPU restatement, fp32, the box's host cores) on a BOUNDED sample of the workload's own job, next to the GPU number.
+    train: one whole step of the bench's batch (4 clips x 7 frames x 64x64: forward + loss + backward + AdamW over every parameter, ~20 s);
+    train_full / train_swin: one step on ONE clip of 7 frames; train_vimeo: one step on a 1 x 3 x 64 x 112 clip (1/16 of the frame area, 3 of 7
+    frames), scaled by pixels; infer: ONE network call on a 5-frame 128 x 128 tile of the 18 x 50-frame calls a sequence needs, scaled."""
     from oracle import cases as C
     from oracle import recipe as R
     from oracle import vmg_oracle as O
     try:
-        ncores = len(os.sched_getaffinity(0))
+        naff = len(os.sched_getaffinity(0))
     except AttributeError:
-        ncores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, ncores)))  # the GPU box gives one GPU a 16-core share; never oversubscribe
-    cfg = C.cfg_reds_few(T=5)
-    shapes, _ = C.load_fixture(os.path.join(ROOT, "tests", "golden", "vmg_reds_few_cfg1.npz"))
-    chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+        naff = os.cpu_count() or 1
+    threads = max(1, min(16, naff))  # the GPU box gives one GPU a 16-core share; never oversubscribe
+    torch.set_num_threads(threads)
+    full = workload == "train_full"
+    mk = C.cfg_reds_full if full else C.cfg_reds_few
+    shapes, _ = C.load_fixture(os.path.join(ROOT, "tests", "golden", "vmg_reds_full.npz" if full else "vmg_reds_few_cfg1.npz"))
+    base_cfg = mk(T=5)
+    if workload == "train_swin":
+        import dataclasses
+        base_cfg = dataclasses.replace(base_cfg, temporal_empty=False)
+        shapes = None
+    chunk_of, window_of = R.vmg_chunk_lookup(base_cfg)
+    if shapes is None:  # (no fixture holds the swin variant's state-dict shapes: take them from the product's own module, weights by recipe as everywhere)
+        import vmg_amd
+        from vmg_amd.data import REDS_FEW_LEVELS
+        net = dict(REDS_FEW_LEVELS, temporal_empty=False)
+        pm = vmg_amd.VMG(num_frames=7, image_size=[64, 64], is_train=True, spynet_pretrained=None, **net)
+        pm.spynet = vmg_amd.SPyNet(None)
+        shapes = {k: list(v.shape) for k, v in pm.state_dict().items()}
     sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
     for k, v in sd.items():
         if v.dtype.is_floating_point and not R.is_buffer(k):
@@ -80,25 +102,47 @@ def cpu_baseline(seconds_budget=30.0):
     leaves = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(leaves, lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
 
-    def one_step(b, t, seed):
-        x = R.synthetic_clip(b, t, 64, 64, seed)
-        y = R.synthetic_target(x)
-        c = C.cfg_reds_few(T=t)
+    def cfg_for(t):
+        c = mk(T=t)
+        if workload == "train_swin":
+            import dataclasses
+            c = dataclasses.replace(c, temporal_empty=False)
+        return c
+
+    def one_step(b, t, h, w, seed, train=True):
+        x = R.synthetic_clip(b, t, h, w, seed)
         t0 = time.time()
-        out = O.vmg_forward(sd, c, x, mutate=False, call_index=1)
-        loss = O.charbonnier_edge_loss(out, y)
-        loss.backward()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
+        if train:
+            y = R.synthetic_target(x)
+            t0 = time.time()
+            out = O.vmg_forward(sd, cfg_for(t), x, mutate=False, call_index=1)
+            O.charbonnier_edge_loss(out, y).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            with torch.no_grad():
+                O.vmg_forward(sd, cfg_for(t), x, mutate=False, call_index=1)
         return time.time() - t0
 
-    warm = one_step(1, 5, 7)
-    print("[bench] cpu_baseline warm-up pass (1x5x64x64) %.1f s" % warm, file=sys.stderr, flush=True)
-    dt = one_step(B_PER_GPU, T, 8)
-    print("[bench] cpu_baseline step (%dx%dx64x64) %.1f s" % (B_PER_GPU, T, dt), file=sys.stderr, flush=True)
-    return {"value": round(B_PER_GPU * T / dt, 4), "unit": "LR-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "one train step of the bench's own job: %d clips x %d frames x 64x64, fp32, forward+loss+backward+AdamW (%.1f s; "
-                      "warm-up pass on 1x5x64x64 before it: %.1f s)" % (B_PER_GPU, T, dt, warm)}
+    warm = one_step(1, 3 if workload != "train_swin" else 4, 64, 64, 7, train=workload != "infer")
+    print("[bench] cpu_baseline warm-up pass %.1f s" % warm, file=sys.stderr, flush=True)
+    if workload == "train":
+        dt = one_step(B_PER_GPU, T, 64, 64, 8)
+        value, sample = B_PER_GPU * T / dt, "one train step of the bench's own job: %d clips x %d frames x 64x64, fp32, forward+loss+backward+AdamW (%.1f s)" % (B_PER_GPU, T, dt)
+    elif workload in ("train_full", "train_swin"):
+        dt = one_step(1, 7, 64, 64, 8)
+        value, sample = 7 / dt, "one train step on ONE clip of 7 frames x 64x64 (the bench's batch is %s), fp32, forward+loss+backward+AdamW (%.1f s)" % ("the same" if full else "4 such clips", dt)
+    elif workload == "train_vimeo":
+        dt = one_step(1, 3, 64, 112, 8)
+        value = 3 * (64 * 112) / (256 * 448) / dt
+        sample = "one train step on a 1 x 3 x 64 x 112 clip (1/16 of the 256 x 448 frame area, 3 of 7 frames), %.1f s; value = 256x448-frame equivalents per second (work is linear in pixels)" % dt
+    else:
+        dt = one_step(1, 5, 128, 128, 8, train=False)
+        value = 100.0 / (18 * 10 * dt)
+        sample = "ONE forward call on a 5-frame 128 x 128 tile (%.1f s); a 100-frame 180 x 320 sequence needs 18 calls of 50 frames: value = 100 / (180 x that time)" % dt
+    print("[bench] cpu_baseline sample %.1f s" % dt, file=sys.stderr, flush=True)
+    return {"value": round(value, 4), "unit": "LR-frames/s", "cores": os.cpu_count() or threads, "threads": threads, "affinity_cores": naff, "kind": "port",
+            "sample": sample + "; warm-up pass before it: %.1f s" % warm}
 
 
 def main():
@@ -109,6 +153,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="train", help="train = BASELINE configs[1] (the metric's own "
                     "configuration, the default); train_full / infer = the per-GPU shard of configs[2] / configs[3]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="VMG(fp8_chains=True): conv1 / conv2 of the recurrent chains' residual blocks in fp8 (e4m3, block-scaled "
+                    "MFMA; SURVEY 8f-4 / BASELINE configs[4]) in the forward pass; the roofline object then prices the fp8 kernel against the 5 PFLOP/s fp8 peak")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
                     "HIP-event roofline needs eager launches, so eager is the default)")
@@ -161,6 +207,7 @@ def main():
     B, Tn, S = wl["batch"], wl["frames"], wl["size"]
     model = build_model(device, wl)
     model.recompute_chains = bool(args.recompute)
+    model.fp8_chains = bool(args.fp8)
     if args.workload == "infer":
         lrs = synthetic_clip(1, Tn, 180, 320, seed=7 + rank, device=device)
 
@@ -206,7 +253,7 @@ def main():
     if not args.no_prof:
         null_us = float(lib.vmg_prof_null_interval_us(50, hip.stream_ptr()))  # event-pair interval of an empty kernel
         hip.check(lib.vmg_prof_select_pixels(hip.ctx(), k1_pixels), "vmg_prof_select_pixels")
-        hip.check(lib.vmg_prof_begin(hip.ctx(), 1, 16, 4096), "vmg_prof_begin")
+        hip.check(lib.vmg_prof_begin(hip.ctx(), 3 if args.fp8 else 1, 16, 4096), "vmg_prof_begin")  # class 1: the bf16 conv3x3 C -> C; 3: the fp8 one
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(lrs, hrs)
@@ -229,15 +276,21 @@ def main():
             avg_s = raw_us * 1e-6
             ach = k1_flops / avg_s / 1e12
             traffic = None  # HBM bytes per launch of this kernel from the PMC passes recorded under profiles/ (not measurable live)
-            if wl["ch"] == 144 and k1_pixels == 32768:
+            if wl["ch"] == 144 and k1_pixels == 32768 and not args.fp8:
                 try:
                     with open(os.path.join(ROOT, "profiles", "r02_b_k1_pmc.json")) as f:
                         traffic = int(json.load(f)["traffic_bytes_per_launch"])
                 except Exception:
                     pass
-            roofline = {"bound": "mfma", "kernel": "conv3x3 %d->%d bf16 on %d px (the weight-streaming kernel conv_ws_kernel: forward + input gradient of the "
-                                                   "recurrent residual chains; both direction sweeps in one launch)" % (wl["ch"], wl["ch"], k1_pixels),
-                        "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            peak = MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS
+            kname = ("conv3x3 %d->%d fp8 (e4m3 operands with E8M0 block scales, v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate) on %d px (convq8_kernel: "
+                     "conv1 / conv2 of the recurrent residual blocks, forward; writes bf16 rows and the next convolution's fp8 records)" if args.fp8 else
+                     "conv3x3 %d->%d bf16 on %d px (the weight-streaming kernel conv_ws_kernel: forward + input gradient of the "
+                     "recurrent residual chains; both direction sweeps in one launch)") % (wl["ch"], wl["ch"], k1_pixels)
+            if args.fp8:
+                traffic = None
+            roofline = {"bound": "mfma", "kernel": kname,
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on tools/k1_traffic.py, profiles/r02_b_k1_pmc.json",
                         "avg_launch_us": round(avg_s * 1e6, 2), "event_interval_us": round(raw_us, 2),
                         "null_kernel_interval_us": round(null_us, 2), "launches_per_step": seen.value // max(1, args.steps),
@@ -253,7 +306,8 @@ def main():
         else "LR-frames/s (sliding-window inference incl. tile blending and uint8 conversion), VMG-REDS-few_levels 4x SR",
         "value": round(value, 3), "unit": "LR-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
+        "dtype": "bf16 (fp8 e4m3 operands in the recurrent chains' forward block convolutions)" if args.fp8 else "bf16",
+        "data": "synthetic (seeded REDS-shaped clips, random-init weights incl. SPyNet)",
         "config": {"workload": wl["name"], "global_batch": world * B, "frames_per_clip": Tn, "lr_size": (list(S) if isinstance(S, tuple) else [S, S]) if train else [180, 320],
                    "parallelism": f"dp{world}", "per_gpu_value": round(value / world, 3), "launch": mode},
         "roofline": roofline,
@@ -261,12 +315,13 @@ def main():
     if train:
         line["config"]["loss"] = float(loss)
         line["config"]["recompute_chains"] = bool(args.recompute)
+        line["config"]["fp8_chains"] = bool(args.fp8)
         line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     if args.workload == "train":
         line["config"]["model_tflops"] = round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and args.workload == "train":
-            line["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -29,6 +29,7 @@ bool vmg_prof_before(int klass, long long pixels, hipStream_t st);
 void vmg_prof_after(hipStream_t st);
 #define VMG_PROF_CONV3X3 1
 #define VMG_PROF_WGRAD 2
+#define VMG_PROF_CONVQ8 3  // the fp8 conv3x3 C -> C (conv_fp8.hip)
 
 #define VMG_CHECK(cond, ...)      \
   do {                            \

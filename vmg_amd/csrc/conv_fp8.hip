@@ -461,7 +461,7 @@ int launch_q8(const ConvQ& k, hipStream_t st) {
   }
   const long long nblk = (long long)k.N * k.tiles_y * k.tiles_x;
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv_q8: bad grid %lld", nblk);
-  const bool prof = vmg_prof_before(VMG_PROF_CONV3X3, (long long)k.N * k.H * k.W, st);
+  const bool prof = vmg_prof_before(VMG_PROF_CONVQ8, (long long)k.N * k.H * k.W, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(G::THREADS), lds, st, kk);
   if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();

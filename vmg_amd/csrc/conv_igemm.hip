@@ -1591,7 +1591,7 @@ int launch_ws(const ConvK& k, int ncb, hipStream_t st) {
   }
   const long long nblk = (long long)k.N * k.tiles_y * k.tiles_x;
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
-  const bool prof = (k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
+  const bool prof = (k.nsrc == 1 && k.src_ch[0] == k.Cout && (k.Cout == 144 || k.Cout == 112)) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(G::THREADS), lds, st, kk);
   if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();
