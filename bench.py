@@ -285,8 +285,9 @@ def main():
             peak = MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS
             kname = ("conv3x3 %d->%d fp8 (e4m3 operands with E8M0 block scales, v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate) on %d px (convq8_kernel: "
                      "conv1 / conv2 of the recurrent residual blocks, forward; writes bf16 rows and the next convolution's fp8 records)" if args.fp8 else
-                     "conv3x3 %d->%d bf16 on %d px (the weight-streaming kernel conv_ws_kernel: forward + input gradient of the "
-                     "recurrent residual chains; both direction sweeps in one launch)") % (wl["ch"], wl["ch"], k1_pixels)
+                     "conv3x3 %d->%d bf16 on %d px (forward + input gradient of the recurrent residual chains, both direction sweeps in one launch: the "
+                     "weight-streaming kernel conv_ws_kernel; at <= 16 384 pixels -- one clip per GPU -- the K-split kernel, whose 64-pixel x 64-channel "
+                     "workgroups fill the chip)") % (wl["ch"], wl["ch"], k1_pixels)
             if args.fp8:
                 traffic = None
             roofline = {"bound": "mfma", "kernel": kname,

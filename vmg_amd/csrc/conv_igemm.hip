@@ -1531,7 +1531,7 @@ int launch_ksplit(const ConvK& k, int ncb, int halo_total, hipStream_t st) {
   VMG_CHECK(nblk > 0 && nblk < (1ll << 31), "conv: bad grid %lld", nblk);
   ConvK kk = k;
   kk.halo_bytes = lds - 16 - NTB * 16 * 4;  // zero slot and bias sit behind max(halo, scratch)
-  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == 144 && k.Cout == 144) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
+  const bool prof = (KS == 3 && sizeof(T) == 2 && k.nsrc == 1 && k.src_ch[0] == k.Cout && (k.Cout == 144 || k.Cout == 112)) && vmg_prof_before(VMG_PROF_CONV3X3, k.M, st);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ncb), dim3(256), lds, st, kk);
   if (prof) vmg_prof_after(st);
   VMG_LAUNCH_CHECK();

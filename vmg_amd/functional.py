@@ -41,6 +41,11 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
     blocks of 80; 30 us on the pixel-split kernel), 77 us at M = 114 688 (84; 96)."""
     if USE_WS and src_ch is not None and not pixel_shuffle:
         t = K.ws_eligible(cout, ks, dtype, src_ch)
+        if t and M <= 16384 and cout in (112, 144):
+            # the recurrence of the full config (one clip per GPU: M = 2 * 64 * 64 = 8 192 pixels) has 64 of the weight-streaming kernel's 128-pixel
+            # tiles for 256 CUs; the K-split kernel's 64-pixel x 64- / 48-channel workgroups fill the chip: 9.1 vs 11.4 us (112 channels), 10.9 vs
+            # 14.2 us (144) at M = 8 192, 11.0 vs 11.4 / 13.2 vs 14.5 us at M = 16 384 (tools/bench_small_conv.py)
+            return (4 if cout == 112 else 3), 1, 2
         if t:
             return t, 1, 3  # weight-streaming kernel: 128-pixel x 144/112-channel workgroups, the CU pulls the weights once
     if dtype == torch.bfloat16 and ks == 3 and cout in (144, 288):
@@ -609,8 +614,8 @@ class _GroupedConv2d(_Fn):
         ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[1] and \
             (bias is None or isinstance(bias, torch.nn.Parameter))
         if ctx.defer:
-            for _ in range(G):
-                ctx.gen = DEFERRED.note_use(weight, bias)
+            # one use; its gradient is written straight into .grad by ONE launch over the G groups in the backward (note_params / written)
+            ctx.gen = DEFERRED.note_params(*([weight] + ([bias] if bias is not None else [])))
             ctx.bias_ref = bias
         ctx.srcs = srcs  # (views of x / of its padded copy: kept for the weight gradient)
         ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre)
@@ -634,8 +639,19 @@ class _GroupedConv2d(_Fn):
                 K.conv_forward([dpre[..., g * og:(g + 1) * og]], pw, None, N, H, W, out=dx[..., g * cg:(g + 1) * cg], mt=mt, deep=deep)
         d_w = d_b = None
         if ctx.defer:
-            for g in range(G):
-                DEFERRED.add(weight, ctx.bias_ref, [srcs[g]], [cg], dpre[..., g * og:(g + 1) * og], ks, N, H, W, gen=ctx.gen, o0=g * og)
+            bias = ctx.bias_ref
+            dW = DEFERRED.grad_of(weight)
+            db = DEFERRED.grad_of(bias) if (bias is not None and bias.requires_grad) else None
+            dys = [dpre[..., g * og:(g + 1) * og] for g in range(G)]
+            if ks == 3 and all(K.conv_wgrad3_multi_ok(srcs[g], dys[g], 3) for g in range(G)):
+                # the G groups are G problems of one shape: ONE launch (and one ordered reduce) instead of G of each -- a group's gradient is a
+                # contiguous row slice of the parameter's gradient
+                probs = [([srcs[g][..., :cg] if srcs[g].shape[-1] != cg else srcs[g]], [dys[g]], dW[g * og:(g + 1) * og],
+                          None if db is None else db[g * og:(g + 1) * og], 1.0) for g in range(G)]
+                K.conv_wgrad3_multi(probs, N, H, W)
+            else:
+                _wgrad_entries([([srcs[g]], (cg,), dys[g], ks, N, H, W, 1.0, g * og) for g in range(G)], dW, db)
+            DEFERRED.written(ctx.gen, *([weight] + ([bias] if bias is not None else [])))
         elif ctx.needs_input_grad[1]:
             d_w = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
             d_b = torch.zeros(O, dtype=torch.float32, device=weight.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
