@@ -115,3 +115,31 @@ def test_ltam_grad_bank_sums_the_calls_that_share_a_key_frame(dtype):
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     for i, (x, y) in enumerate(zip(a, b)):
         assert float((x.float() - y.float()).abs().max()) <= tol * max(1.0, float(y.float().abs().max())), f"gradient {i}"
+
+
+def test_flow_warp_backward_with_many_clamped_pixels_bf16_vs_fp32():
+    """Border padding with large flows: whole rows / columns of output pixels clamp onto the same border pixels, so a source pixel collects
+    dozens of contributions.  The bf16 path accumulates them in fp32 and rounds once: its dx must agree with the fp32 path's to bf16 rounding
+    (2^-8 of each element), also where the sums are large -- a bf16 running sum (round 2) drifted by several percent there."""
+    R, O, C, FH = _mods()
+    n, h, w, c = 1, 24, 40, 64
+    x = R.seeded((n, h, w, c), 361).to(torch.bfloat16)
+    flow = R.seeded((n, h, w, 2), 362, 1.0)
+    flow[:, :, : w // 2, 0] -= 60.0   # the left half samples far left of the image: clamped onto column 0
+    flow[:, : h // 3, :, 1] -= 40.0   # the top third: clamped onto row 0
+    gy = (R.seeded((n, h, w, c), 363).abs() + 0.5).to(torch.bfloat16)  # same-sign gradients: the border sums grow to ~h * w / 6 terms
+
+    def run(dt):
+        xd = x.cuda().to(dt).requires_grad_(True)
+        fd = flow.cuda().requires_grad_(True)
+        out = FH.grid_sample_flow(xd, fd, "bilinear", "border")
+        gx, gf = torch.autograd.grad(out, (xd, fd), gy.cuda().to(dt))
+        return gx.float().cpu(), gf.cpu()
+    g16, f16 = run(torch.bfloat16)
+    g32, f32 = run(torch.float32)
+    assert float(g32.abs().max()) > 50.0  # the clamped border really collects many contributions
+    assert float(((g16 - g32).abs() / (g32.abs() + 1e-3)).max()) <= 2 ** -8 + 1e-3
+    assert float((f16 - f32).abs().max()) <= 2e-2 * max(1.0, float(f32.abs().max()))
+    # and two bf16 runs agree to the fp32 sum's arrival-order rounding
+    g16b, _ = run(torch.bfloat16)
+    assert float(((g16 - g16b).abs() / (g16.abs() + 1e-3)).max()) <= 2 ** -7

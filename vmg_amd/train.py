@@ -610,7 +610,7 @@ class TrainStep:
         from . import functional as FH
         FH.flush_deferred_wgrads()
 
-    def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2, replayer: bool = False):
+    def capture(self, lrs: torch.Tensor, hrs: torch.Tensor, warmup: int = 2, replayer: bool = False, before_capture=None):
         """Capture one whole training step (forward, loss, backward, deferred weight gradients, AdamW) into a hipGraph.
 
         Replaying the step's ~2 000 launches from a graph removes the Python / launch overhead.  The weight packs are rebuilt INSIDE the
@@ -636,6 +636,9 @@ class TrainStep:
         torch.cuda.synchronize()
         if not isinstance(self.opt, FlatAdamW):
             FH.clear_pack_cache()  # (no repack_all in this path: every pack is recorded where it is first needed)
+        if before_capture is not None:
+            before_capture()  # (e.g. arm the library's HIP-event sampler: event records issued during the capture become nodes of the graph and are
+            #                    re-recorded by every replay, so a replayed step can still be timed kernel by kernel)
         self.graph = torch.cuda.CUDAGraph(keep_graph=replayer)
         with torch.cuda.graph(self.graph):
             self._loss = self._eager(*self._static)
