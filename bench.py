@@ -285,9 +285,10 @@ def main():
             avg_s = raw_us * 1e-6
             ach = k1_flops / avg_s / 1e12
             traffic = None  # HBM bytes per launch of this kernel from the PMC passes recorded under profiles/ (not measurable live)
-            if wl["ch"] == 144 and k1_pixels == 32768 and not args.fp8:
+            pmc_file = "r03_g_q8_pmc.json" if args.fp8 else "r03_g_k1_pmc.json"
+            if wl["ch"] == 144 and k1_pixels == 32768:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r02_b_k1_pmc.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         traffic = int(json.load(f)["traffic_bytes_per_launch"])
                 except Exception:
                     pass
@@ -297,11 +298,9 @@ def main():
                      "conv3x3 %d->%d bf16 on %d px (forward + input gradient of the recurrent residual chains, both direction sweeps in one launch: the "
                      "weight-streaming kernel conv_ws_kernel; at <= 16 384 pixels -- one clip per GPU -- the K-split kernel, whose 64-pixel x 64-channel "
                      "workgroups fill the chip)") % (wl["ch"], wl["ch"], k1_pixels)
-            if args.fp8:
-                traffic = None
             roofline = {"bound": "mfma", "kernel": kname,
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on tools/k1_traffic.py, profiles/r02_b_k1_pmc.json",
+                        "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE on tools/%s, profiles/%s (the kernel and shape in isolation)" % ("q8_traffic.py" if args.fp8 else "k1_traffic.py", pmc_file),
                         "avg_launch_us": round(avg_s * 1e6, 2), "event_interval_us": round(raw_us, 2),
                         "null_kernel_interval_us": round(null_us, 2), "launches_per_step": seen.value // max(1, args.steps),
                         "samples": n.value}
