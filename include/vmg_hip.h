@@ -437,6 +437,23 @@ int vmg_q8_quantize(const void* x, int64_t x_ps, void* out, int64_t M, int C, vo
 int64_t vmg_convq8_pack_bytes(int Cout, int Cin);
 int vmg_convq8_pack(const float* w, int O, int I, int transpose_flip, void* packed, void* stream);
 int vmg_convq8_fwd(const vmg_convq8_desc* d, void* stream);
+/* The fp8 part of ResidualBlocksWithInputConv (models/trajectory.py:16-52, 165-221) from one call: per block t_k = relu(conv1(q)),
+ * y_{k+1} = y_k + r * conv2(q(t_k)).  q0: records of y[0]; y: nblk + 1 bf16 tensors (y[0] given); t: nblk bf16 tensors or null (not kept);
+ * qa, qb: scratch record buffers (N*H*W * vmg_q8_record_bytes(C) bytes each; qa may equal q0). */
+typedef struct vmg_chainq8_desc {
+  int N, H, W, C, nblk;
+  const void* q0;
+  void* qa;
+  void* qb;
+  void* const* packed1;
+  void* const* bias1;
+  void* const* packed2;
+  void* const* bias2;
+  void* const* y;
+  void* const* t;
+  float r_scaling;
+} vmg_chainq8_desc;
+int vmg_resblock_chain_fwd_q8(const vmg_chainq8_desc* c, void* stream);
 
 /* ---- clip_grad_norm_ over a flat fp32 gradient buffer (reference: torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) as
  * called in tools/Trainer.py:141-143, 166-167 when train.if_grad_clip is set) -------------------------------------------------

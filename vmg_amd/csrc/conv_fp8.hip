@@ -530,3 +530,26 @@ extern "C" int vmg_convq8_fwd(const vmg_convq8_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   return nct == 9 ? launch_q8<9, 5>(k, st) : launch_q8<7, 4>(k, st);
 }
+
+// All launches of a residual chain's fp8 part from ONE call (the Python loop over 30 convolutions made the inference path host-bound):
+//   for k: t_k = relu(conv1_k(q)) -> records qb (+ bf16 t[k] when kept);  y_{k+1} = y_k + r * conv2_k(qb) -> bf16 y[k+1] (+ records qa for the next block)
+// q0: the records of y[0]; qa / qb: two scratch record buffers (qa may be q0 itself).
+extern "C" int vmg_resblock_chain_fwd_q8(const vmg_chainq8_desc* c, void* stream) {
+  VMG_CHECK(c && c->nblk >= 1 && c->q0 && c->qa && c->qb && c->y && c->packed1 && c->packed2 && c->bias1 && c->bias2, "resblock_chain_fwd_q8: bad descriptor");
+  vmg_convq8_desc d;
+  const void* q = c->q0;
+  for (int k = 0; k < c->nblk; ++k) {
+    memset(&d, 0, sizeof(d));
+    d.N = c->N; d.H = c->H; d.W = c->W; d.Cin = c->C; d.Cout = c->C; d.alpha = 1.f;
+    d.src = q; d.packed = c->packed1[k]; d.bias = (const float*)c->bias1[k]; d.out = c->t ? c->t[k] : nullptr; d.out_ps = c->C; d.outq = c->qb; d.act = VMG_ACT_RELU;
+    int rc = vmg_convq8_fwd(&d, stream);
+    if (rc) return rc;
+    memset(&d, 0, sizeof(d));
+    d.N = c->N; d.H = c->H; d.W = c->W; d.Cin = c->C; d.Cout = c->C;
+    d.src = c->qb; d.packed = c->packed2[k]; d.bias = (const float*)c->bias2[k]; d.out = c->y[k + 1]; d.out_ps = c->C;
+    d.outq = k + 1 < c->nblk ? c->qa : nullptr; d.res = c->y[k]; d.res_ps = c->C; d.alpha = c->r_scaling; d.act = VMG_ACT_NONE;
+    if ((rc = vmg_convq8_fwd(&d, stream))) return rc;
+    q = c->qa;
+  }
+  return 0;
+}

@@ -703,14 +703,8 @@ def _chain_forward_fp8(srcs, params, r_scaling, keep_t: bool):
     C = w0.shape[0]
     t0_, m0_, d0_ = choose_tiling(M, C, 3, dt, src_ch)
     y0, _ = K.conv_forward(srcs, packed(w0, dt, "fwd", src_ch, tiles=t0_, deep=d0_), b0, N, H, W, act=hip.ACT_LRELU, slope=0.1, mt=m0_, deep=d0_)
-    ys, ts = [y0], []
-    q = K.q8_quantize(y0) if nblk else None
-    for k in range(nblk):
-        w1, b1, w2, b2 = params[2 + 4 * k: 6 + 4 * k]
-        t, tq = K.conv_q8_forward(q, packed_q8(w1), b1, N, H, W, act=hip.ACT_RELU, want_bf16=keep_t, want_q8=True)
-        y, q = K.conv_q8_forward(tq, packed_q8(w2), b2, N, H, W, alpha=r_scaling, res=ys[k], want_bf16=True, want_q8=k + 1 < nblk)
-        ts.append(t)
-        ys.append(y)
+    ys, ts = K.resblock_chain_forward_q8(y0, [packed_q8(params[2 + 4 * k]) for k in range(nblk)], [params[3 + 4 * k] for k in range(nblk)],
+                                         [packed_q8(params[4 + 4 * k]) for k in range(nblk)], [params[5 + 4 * k] for k in range(nblk)], r_scaling, keep_t)
     FP8_STATS["chains"] += 1
     return ys, ts
 

@@ -60,6 +60,16 @@ class ConvQ8Desc(ctypes.Structure):
     ]
 
 
+class ChainQ8Desc(ctypes.Structure):
+    """vmg_chainq8_desc (include/vmg_hip.h)."""
+    _fields_ = [
+        ("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("nblk", c_int),
+        ("q0", c_void_p), ("qa", c_void_p), ("qb", c_void_p),
+        ("packed1", POINTER(c_void_p)), ("bias1", POINTER(c_void_p)), ("packed2", POINTER(c_void_p)), ("bias2", POINTER(c_void_p)),
+        ("y", POINTER(c_void_p)), ("t", POINTER(c_void_p)), ("r_scaling", c_float),
+    ]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol of include/vmg_hip.h must be listed (tests/test_abi.py checks)
@@ -132,6 +142,7 @@ SIGNATURES = {
     "vmg_convq8_pack_bytes": (c_int64, [c_int, c_int]),
     "vmg_convq8_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vmg_convq8_fwd": (c_int, [POINTER(ConvQ8Desc), c_void_p]),
+    "vmg_resblock_chain_fwd_q8": (c_int, [POINTER(ChainQ8Desc), c_void_p]),
     "vmg_grad_clip_ws_bytes": (c_int64, []),
     "vmg_grad_clip_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "vmg_tile_accumulate": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1025,3 +1025,31 @@ def conv_q8_forward(src: torch.Tensor, pw: PackedQ8, bias: Optional[torch.Tensor
     d.act, d.slope, d.alpha = act, slope, alpha
     hip.check(hip.lib().vmg_convq8_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_convq8_fwd")
     return o, oq
+
+
+def resblock_chain_forward_q8(y0: torch.Tensor, pw1, b1, pw2, b2, r_scaling: float, keep_t: bool):
+    """The fp8 part of a residual chain as ONE C call (vmg_resblock_chain_fwd_q8): y0 (N,H,W,C) bf16 -> (ys, ts); ts entries are None when not kept."""
+    hip.require_cuda(y0, *b1, *b2)
+    N, H, W, C = y0.shape
+    nblk = len(pw1)
+    if y0.dtype != torch.bfloat16 or not y0.is_contiguous() or len(pw2) != nblk or any(p.cout != C or p.cin != C for p in list(pw1) + list(pw2)):
+        raise HipError("resblock_chain_forward_q8: contiguous bf16 y0 and C -> C fp8 packs expected")
+    for b in list(b1) + list(b2):
+        if b.dtype != torch.float32 or b.numel() != C or not b.is_contiguous():
+            raise HipError("resblock_chain_forward_q8: biases must be contiguous fp32 of length C")
+    rec = q8_record_bytes(C)
+    q = q8_quantize(y0)
+    qb = torch.empty((N, H, W, rec), dtype=torch.uint8, device=y0.device)
+    blk = torch.empty((nblk * (2 if keep_t else 1), N, H, W, C), dtype=torch.bfloat16, device=y0.device).unbind(0)
+    ys = [y0] + list(blk[:nblk])
+    ts = list(blk[nblk:]) if keep_t else [None] * nblk
+    d = hip.ChainQ8Desc()
+    d.N, d.H, d.W, d.C, d.nblk = N, H, W, C, nblk
+    d.q0, d.qa, d.qb = q.data_ptr(), q.data_ptr(), qb.data_ptr()
+    keep = [_parr([p.buf for p in pw1]), _parr(list(b1)), _parr([p.buf for p in pw2]), _parr(list(b2)), _parr(ys), _parr(ts) if keep_t else None]
+    d.packed1, d.bias1, d.packed2, d.bias2, d.y = keep[:5]
+    if keep_t:
+        d.t = keep[5]
+    d.r_scaling = r_scaling
+    hip.check(hip.lib().vmg_resblock_chain_fwd_q8(ctypes.byref(d), hip.stream_ptr()), "vmg_resblock_chain_fwd_q8")
+    return ys, ts
