@@ -211,9 +211,11 @@ def main():
     if args.workload == "infer":
         lrs = synthetic_clip(1, Tn, 180, 320, seed=7 + rank, device=device)
 
+        net = infer.GraphedModel(model) if args.graph else model  # --graph: every network call replayed from one captured graph (same bits)
+
         def step(_a, _b):
             with torch.no_grad():
-                return infer.to_uint8(infer.test_clips(model, lrs, 50, 25, [128, 128], 20, 4))
+                return infer.to_uint8(infer.test_clips(net, lrs, 50, 25, [128, 128], 20, 4))
         hrs = None
         k1_pixels = 2 * 1 * S * S
     else:
@@ -323,6 +325,9 @@ def main():
     }
     if train:
         line["config"]["loss"] = float(loss)
+    elif args.graph:
+        line["config"]["launch"] = "hipgraph (vmg_amd.infer.GraphedModel: one captured network call, replayed per tile)"
+        line["roofline"] = None
         line["config"]["recompute_chains"] = bool(args.recompute)
         line["config"]["fp8_chains"] = bool(args.fp8)
         line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)

@@ -113,3 +113,28 @@ def test_infer_refuses_cpu():
     from vmg_amd import hip, infer
     with pytest.raises(hip.HipError):
         infer.test_image(lambda x: x, torch.zeros(1, 1, 3, 16, 16), [16, 16], 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graphed_model_gives_the_same_bits_and_keeps_the_call_count(dtype):
+    """infer.GraphedModel: the network call replayed from a captured graph.  The sliding-window result must equal the eager one bit for bit -- including
+    the statefulness: the warm-up calls the capture needs must not count as calls (the mixer weights are restored), and every replay must
+    decay the weights once like an eager call does."""
+    from oracle import cases as C
+    from tests.util import build_product
+    from vmg_amd import infer
+    case = C.CASES["infer_vmg_clips"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "infer_vmg_clips.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = case["inputs"]()["x"].cuda()
+    res = []
+    for graphed in (False, True):
+        m = build_product(case["cfg"], dtype)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        net = infer.GraphedModel(m) if graphed else m
+        out = infer.test_clips(net, x, 3, 1, [64, 64], 8, 4)
+        res.append((out.float().cpu(), {k: v.clone() for k, v in m.state_dict().items() if "mlp_h.0.weight" in k or "mlp_w.0.weight" in k}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k  # the same number of decays has been applied

@@ -780,7 +780,10 @@ class VMG(nn.Module):
         B, D, C, H, W = x.size()
         in_dtype = x.dtype
         x = x.float()
-        self.check_frames_mirror(lrs=x)
+        if self.__dict__.get("_mirror_known") is None:
+            self.check_frames_mirror(lrs=x)  # (a host decision on device data: infer.GraphedModel takes it before the replay and passes it in)
+        else:
+            self.frames_mirror = bool(self._mirror_known)
         up = F.interpolate(x.reshape(B * D, C, H, W), scale_factor=4, mode="bilinear", align_corners=False)  # == trilinear with D kept
         Hp = int(np.ceil(H / self.scale)) * self.scale
         Wp = int(np.ceil(W / self.scale)) * self.scale
