@@ -1,5 +1,5 @@
 """Which ops issue the full-size strided copies / adds / cats of a train step?  One profiled step (CPU activity, shapes); prints every aten::copy_ /
-aten::add / aten::add_ / aten::cat / aten::mul whose largest input has >= 10 M elements with its chain of enclosing ops.  python tools/big_copies.py"""
+aten::add / aten::add_ / aten::cat / aten::mul whose largest input has >= 4 M elements with its chain of enclosing ops.  python tools/big_copies.py"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,7 +38,7 @@ for ev in prof.events():
                     for v in t:
                         n *= v
                     big = max(big, n)
-    if big < 10_000_000:
+    if big < 4_000_000:
         continue
     chain, p = [], ev.cpu_parent
     while p is not None and len(chain) < 4:
