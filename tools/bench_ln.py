@@ -32,6 +32,9 @@ into = (torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"))
 tf = timed(lambda: K.layernorm_forward(x, w, b, 1e-5))
 tb = timed(lambda: K.layernorm_backward(dy, x, mean, rstd, w, into=into))
 ta = timed(lambda: K.layernorm_backward(dy, x, mean, rstd, w, into=into, add=add))
+dys = [torch.randn(M, C, device="cuda").to(dt) for _ in range(5)]
+t5 = timed(lambda: K.layernorm_backward(dys, x, mean, rstd, w, into=into, add=add))
 mb = M * C * 2 / 1e6
 print("forward %6.1f us (%.0f GB/s)   backward %6.1f us (%.0f GB/s)   backward + add %6.1f us (%.0f GB/s)" %
       (tf, 2 * mb / tf * 1e3, tb, 3 * mb / tb * 1e3, ta, 4 * mb / ta * 1e3), flush=True)
+print("backward with five output gradients + add %6.1f us (%.0f GB/s)" % (t5, 8 * mb / t5 * 1e3), flush=True)

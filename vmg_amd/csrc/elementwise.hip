@@ -191,74 +191,91 @@ __device__ __forceinline__ long long ln_src_elem(const LnMap& m, long long row, 
 }
 
 // NV = vectors per lane (1, 2 or 4): the register arrays are exactly as long as the row needs, the affine weights of a lane's channels
-// are loaded once, and the next row's vectors are fetched before the current row's reductions (one row of loads always in flight).
-template <typename T, int V, int G, int NV>
+// are loaded once.
+template <typename T, int V, int G, int NV, bool MAPPED>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, long long M,
-                                                            int C, float eps, const LnMap map) {
+                                                            int C, float eps, const LnMap map_arg) {
+  // MAPPED = false: contiguous rows.  As a run-time mode the 64-bit divisions of the space<->depth maps were computed for every vector of
+  // every row (the compiler hoists them out of the mode branch): 24 us instead of 12 for the plain LayerNorm at M = 114 688
+  const LnMap map = MAPPED ? map_arg : LnMap{0, 0, 0, 0};
   const int nvec = C / V;
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
   const long long stride = (long long)gridDim.x * groups_per_block;
+  // the affine weights of a lane's channels, through LDS: read straight from memory they were 2 * NV * V four-byte load instructions per wave
+  // (32 at C = 144), 16 cycles of address processing each -- with 24 waves per CU that prologue cost 10 of the kernel's 24 us
+  extern __shared__ float ln_aff[];  // [2][C]
+  for (int i = threadIdx.x; i < C; i += 256) {
+    ln_aff[i] = w[i];
+    ln_aff[C + i] = b[i];
+  }
+  __syncthreads();
   float wr[NV][V], br[NV][V];
 #pragma unroll
   for (int k = 0; k < NV; ++k)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const int c = (gl + k * G) * V + e;
-      wr[k][e] = c < C ? w[c] : 0.f;
-      br[k][e] = c < C ? b[c] : 0.f;
+      wr[k][e] = c < C ? ln_aff[c] : 0.f;
+      br[k][e] = c < C ? ln_aff[C + c] : 0.f;
     }
-  long long row = blockIdx.x * groups_per_block + threadIdx.x / G;
-  VecN<T, V> nxt[NV];
-  auto fetch = [&](long long r) __attribute__((always_inline)) {
+  // STRAIGHT-LINE body, R rows per lane group and iteration: all loads of the R rows first (row indices clamped, so that no load sits behind
+  // a branch), then the reductions, then the stores.  The earlier form -- the next row prefetched under `if (row + stride < M)` inside a
+  // per-lane loop -- compiled to `s_waitcnt vmcnt(0)` at every join: each iteration waited for its own STORES, and the kernel ran at
+  // 2.7 TB/s (24 us at M = 114 688, C = 144) where this form reaches 5.8 (tools/ubench/ln_probe.cpp)
+  constexpr int R = 2;
+  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += R * stride) {
+    VecN<T, V> buf[R][NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) nxt[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, r, vi * V, C));
-    }
-  };
-  if (row < M) fetch(row);
-  for (; row < M; row += stride) {
-    VecN<T, V> buf[NV];
+    for (int r = 0; r < R; ++r) {
+      const long long rr = row + r * stride < M ? row + r * stride : M - 1;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) buf[k] = nxt[k];
-    if (row + stride < M) fetch(row + stride);
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if (gl + k * G < nvec) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) s += to_f32(buf[k].v[e]);
+      for (int k = 0; k < NV; ++k) {
+        const int vi = gl + k * G;
+        if (vi < nvec) buf[r][k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, rr, vi * V, C));
       }
     }
-    const float mu = group_sum<G>(s) / C;
-    float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if (gl + k * G < nvec) {
+    for (int r = 0; r < R; ++r) {
+      const long long rr = row + r * stride;
+      const bool live = rr < M;
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float d = to_f32(buf[k].v[e]) - mu;
-          q += d * d;
+      for (int k = 0; k < NV; ++k) {
+        if (gl + k * G < nvec) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) s += to_f32(buf[r][k].v[e]);
         }
       }
-    }
-    const float rs = rsqrtf(group_sum<G>(q) / C + eps);
-    if (gl == 0 && mean) {
-      mean[row] = mu;
-      rstd[row] = rs;
-    }
-    T* yr = y + row * C;
+      const float mu = group_sum<G>(s) / C;
+      float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) {
-        VecN<T, V> o;
+      for (int k = 0; k < NV; ++k) {
+        if (gl + k * G < nvec) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>((to_f32(buf[k].v[e]) - mu) * rs * wr[k][e] + br[k][e]);
-        reinterpret_cast<VecN<T, V>*>(yr)[vi] = o;
+          for (int e = 0; e < V; ++e) {
+            const float d = to_f32(buf[r][k].v[e]) - mu;
+            q += d * d;
+          }
+        }
+      }
+      const float rs = rsqrtf(group_sum<G>(q) / C + eps);
+      if (live && gl == 0 && mean) {
+        mean[rr] = mu;
+        rstd[rr] = rs;
+      }
+      T* yr = y + rr * C;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int vi = gl + k * G;
+        if (live && vi < nvec) {
+          VecN<T, V> o;
+#pragma unroll
+          for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>((to_f32(buf[r][k].v[e]) - mu) * rs * wr[k][e] + br[k][e]);
+          reinterpret_cast<VecN<T, V>*>(yr)[vi] = o;
+        }
       }
     }
   }
@@ -269,13 +286,19 @@ struct LnMore {
   int n;
 };
 
-template <typename T, int V, int G, int NV>
+// SPEC: 0 = `add` / `more` looked at at run time (a load behind a run-time branch, even a wave-uniform one, is followed by `s_waitcnt
+// vmcnt(0)`: the generic form serialises its loads); 2 = add, no further gradients; 3 = add + four further gradients -- the two forms the
+// TAB blocks use (functional.layer_norm_skip / layer_norm_fan), compiled without those branches
+template <typename T, int V, int G, int NV, bool MAPPED, int SPEC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, T* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, long long M, int C,
-                                                            const LnMap map, const T* __restrict__ add, float* __restrict__ ws,
+                                                            const LnMap map_arg, const T* __restrict__ add, float* __restrict__ ws,
                                                             unsigned int* __restrict__ counter, const LnMore more) {
+  const LnMap map = MAPPED ? map_arg : LnMap{0, 0, 0, 0};  // (see layernorm_fwd_kernel)
+  const bool has_add = SPEC == 0 ? add != nullptr : true;
+  const int nmore = SPEC == 0 ? more.n : (SPEC == 3 ? 4 : 0);
   // more: up to four FURTHER gradients of the LayerNorm output (contiguous rows, like dy): a normalised tensor that feeds several consumers
   // (the MorphFC mixer reads LN2(x) five times: H branch, W branch, RCAB conv, RCAB residual, tanh gate) collects one gradient per consumer;
   // they are summed here in fp32 on the way in -- autograd's pairwise adds cost three passes each over the (N, C) tensor.
@@ -285,6 +308,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   const int gl = threadIdx.x % G;
   const long long groups_per_block = 256 / G;
   const long long stride = (long long)gridDim.x * groups_per_block;
+  extern __shared__ float smw[];  // [4 waves][2][C]: the parameter-gradient sums at the end; first the affine weights on their way to the lanes
+  for (int i = threadIdx.x; i < C; i += 256) smw[i] = w[i];  // (through LDS: see layernorm_fwd_kernel)
+  __syncthreads();
   float pdw[NV][V], pdb[NV][V], wr[NV][V];
 #pragma unroll
   for (int k = 0; k < NV; ++k)
@@ -292,80 +318,85 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int e = 0; e < V; ++e) {
       pdw[k][e] = pdb[k][e] = 0.f;
       const int c = (gl + k * G) * V + e;
-      wr[k][e] = c < C ? w[c] : 0.f;
+      wr[k][e] = c < C ? smw[c] : 0.f;
     }
-  long long row = blockIdx.x * groups_per_block + threadIdx.x / G;
-  VecN<T, V> nx[NV], ng[NV];
-  float nmu = 0.f, nrs = 0.f;
-  auto fetch = [&](long long r) __attribute__((always_inline)) {
-    nmu = mean[r];
-    nrs = rstd[r];
+  // straight-line body like layernorm_fwd_kernel: the loads of R rows (clamped indices), the reductions, the stores.  The parameter-gradient
+  // sums skip a clamped (repeated) row by a zero factor
+  constexpr int R = 2;
+  for (long long row = blockIdx.x * groups_per_block + threadIdx.x / G; row < M; row += R * stride) {
+    VecN<T, V> bx[R][NV], bg[R][NV], ba[R][NV];
+    float rmu[R], rrs[R];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) {
-        nx[k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, r, vi * V, C));
-        ng[k] = reinterpret_cast<const VecN<T, V>*>(dy + r * C)[vi];
-        if (more.n) {  // (wave-uniform)
-          float acc[V];
+    for (int r = 0; r < R; ++r) {
+      const long long rr = row + r * stride < M ? row + r * stride : M - 1;
+      rmu[r] = mean[rr];
+      rrs[r] = rstd[rr];
 #pragma unroll
-          for (int e = 0; e < V; ++e) acc[e] = to_f32(ng[k].v[e]);
+      for (int k = 0; k < NV; ++k) {
+        const int vi = gl + k * G;
+        if (vi < nvec) {
+          bx[r][k] = *reinterpret_cast<const VecN<T, V>*>(x + ln_src_elem(map, rr, vi * V, C));
+          bg[r][k] = reinterpret_cast<const VecN<T, V>*>(dy + rr * C)[vi];
+          if (has_add) ba[r][k] = reinterpret_cast<const VecN<T, V>*>(add + rr * C)[vi];  // (wave-uniform)
+          if (nmore) {  // (wave-uniform)
+            float acc[V];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < more.n) {
-              const VecN<T, V> t = reinterpret_cast<const VecN<T, V>*>(reinterpret_cast<const T*>(more.p[j]) + r * C)[vi];
+            for (int e = 0; e < V; ++e) acc[e] = to_f32(bg[r][k].v[e]);
 #pragma unroll
-              for (int e = 0; e < V; ++e) acc[e] += to_f32(t.v[e]);
+            for (int j = 0; j < 4; ++j) {
+              if (j < nmore) {
+                const VecN<T, V> t = reinterpret_cast<const VecN<T, V>*>(reinterpret_cast<const T*>(more.p[j]) + rr * C)[vi];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += to_f32(t.v[e]);
+              }
             }
+#pragma unroll
+            for (int e = 0; e < V; ++e) bg[r][k].v[e] = from_f32<T>(acc[e]);
           }
-#pragma unroll
-          for (int e = 0; e < V; ++e) ng[k].v[e] = from_f32<T>(acc[e]);
         }
       }
     }
-  };
-  if (row < M) fetch(row);
-  for (; row < M; row += stride) {
-    const float mu = nmu, rs = nrs;
-    VecN<T, V> bx[NV], bg[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { bx[k] = nx[k]; bg[k] = ng[k]; }
-    if (row + stride < M) fetch(row + stride);  // the next row's loads fly while this row is reduced and written
-    float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dy * w
+    for (int r = 0; r < R; ++r) {
+      const long long rr = row + r * stride;
+      const bool live = rr < M;
+      const float keep = live ? 1.f : 0.f;
+      const float mu = rmu[r], rs = rrs[r];
+      float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dy * w
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if (gl + k * G < nvec) {
+      for (int k = 0; k < NV; ++k) {
+        if (gl + k * G < nvec) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
-          const float d = to_f32(bg[k].v[e]);
-          const float g = d * wr[k][e];
-          s1 += g;
-          s2 += g * xh;
-          pdw[k][e] += d * xh;
-          pdb[k][e] += d;
+          for (int e = 0; e < V; ++e) {
+            const float xh = (to_f32(bx[r][k].v[e]) - mu) * rs;
+            const float d = to_f32(bg[r][k].v[e]) * keep;
+            const float g = d * wr[k][e];
+            s1 += g;
+            s2 += g * xh;
+            pdw[k][e] += d * xh;
+            pdb[k][e] += d;
+          }
         }
       }
-    }
-    s1 = group_sum<G>(s1) / C;
-    s2 = group_sum<G>(s2) / C;
+      s1 = group_sum<G>(s1) / C;
+      s2 = group_sum<G>(s2) / C;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int vi = gl + k * G;
-      if (vi < nvec) {
-        VecN<T, V> o;
+      for (int k = 0; k < NV; ++k) {
+        const int vi = gl + k * G;
+        if (live && vi < nvec) {
+          VecN<T, V> o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          const float xh = (to_f32(bx[k].v[e]) - mu) * rs;
-          const float g = to_f32(bg[k].v[e]) * wr[k][e];
-          o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
+          for (int e = 0; e < V; ++e) {
+            const float xh = (to_f32(bx[r][k].v[e]) - mu) * rs;
+            const float g = to_f32(bg[r][k].v[e]) * wr[k][e];
+            o.v[e] = from_f32<T>(rs * (g - s1 - xh * s2));
+          }
+          if (has_add) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>(to_f32(o.v[e]) + to_f32(ba[r][k].v[e]));
+          }
+          *reinterpret_cast<VecN<T, V>*>(dx + ln_src_elem(map, rr, vi * V, C)) = o;
         }
-        if (add) {
-          const VecN<T, V> av = reinterpret_cast<const VecN<T, V>*>(add + row * C)[vi];
-#pragma unroll
-          for (int e = 0; e < V; ++e) o.v[e] = from_f32<T>(to_f32(o.v[e]) + to_f32(av.v[e]));
-        }
-        *reinterpret_cast<VecN<T, V>*>(dx + ln_src_elem(map, row, vi * V, C)) = o;
       }
     }
   }
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   if (dw == nullptr) return;  // (tools/bench_ln.py, VMG_LN_DBG=1: the kernel without its parameter-gradient tail)
 #endif
   // (LDS float atomics from all 256 threads cost 12 us here: the row groups of a wave are summed with shuffles, the four waves through LDS)
-  extern __shared__ float smw[];  // [4 waves][2][C]
+  __syncthreads();  // (every lane has taken its affine weights out of smw long ago; the barrier orders the slowest wave's reads before the sums)
   const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -538,15 +569,19 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
   const int G = ln_group(nvec);
   VMG_CHECK(nvec <= G * LN_MAXV, "layernorm: C = %d too large", C);
   const long long rows_per_block = 256 / G;
-  const int blocks = (int)(cdiv64(M, rows_per_block * 4) > 1536 ? 1536 : cdiv64(M, rows_per_block * 4));  // several rows per lane group: the hoisted affine weights and the prefetch pay
+  // several rows per lane group (the hoisted affine weights pay), and no more blocks than are RESIDENT at once (4 per CU at <= 128 registers):
+  // with 1 536 blocks and 4-5 resident per CU a second, mostly empty round of blocks doubled the kernel's duration
+  const int blocks = (int)(cdiv64(M, rows_per_block * 4) > 1024 ? 1024 : cdiv64(M, rows_per_block * 4));
   const int nv = (nvec + G - 1) / G;
-#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps, map)
+#define LN_LAUNCH_M(GG, NV, MP) hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, GG, NV, MP>), dim3(blocks), dim3(256), 2 * C * 4, st, (const T*)x, w, b, (T*)y, mean, rstd, M, C, eps, map)
+#define LN_LAUNCH(GG, NV) do { if (map.mode == 0) LN_LAUNCH_M(GG, NV, false); else LN_LAUNCH_M(GG, NV, true); } while (0)
 #define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
   if (G == 16) LN_LAUNCH_G(16);
   else if (G == 32) LN_LAUNCH_G(32);
   else LN_LAUNCH_G(64);
 #undef LN_LAUNCH_G
 #undef LN_LAUNCH
+#undef LN_LAUNCH_M
   VMG_LAUNCH_CHECK();
   return 0;
 }
@@ -567,13 +602,19 @@ static int ln_bwd_t(const void* dy, const void* x, const float* mean, const floa
   const int nv = (nvec + G - 1) / G;
   unsigned int* counter = nullptr;
   float* ws = (blocks > LN_SUB && C <= 2048) ? ln_workspace(st, &counter) : nullptr;  // (null: plain float atomics on dw / db)
-#define LN_LAUNCH(GG, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add, ws, counter, more)
+#define LN_LAUNCH_M(GG, NV, MP, SP) hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, GG, NV, MP, SP>), dim3(blocks), dim3(256), lds, st, (const T*)dy, (const T*)x, mean, rstd, w, (T*)dx, dw, db, M, C, map, (const T*)add, ws, counter, more)
+#define LN_LAUNCH(GG, NV) do { \
+    if (map.mode != 0) LN_LAUNCH_M(GG, NV, true, 0); \
+    else if constexpr (sizeof(T) == 2 && V == 8) { \
+      if (add && more.n == 0) LN_LAUNCH_M(GG, NV, false, 2); else if (add && more.n == 4) LN_LAUNCH_M(GG, NV, false, 3); else LN_LAUNCH_M(GG, NV, false, 0); \
+    } else LN_LAUNCH_M(GG, NV, false, 0); } while (0)
 #define LN_LAUNCH_G(GG) do { if (nv == 1) LN_LAUNCH(GG, 1); else if (nv == 2) LN_LAUNCH(GG, 2); else LN_LAUNCH(GG, 4); } while (0)
   if (G == 16) LN_LAUNCH_G(16);
   else if (G == 32) LN_LAUNCH_G(32);
   else LN_LAUNCH_G(64);
 #undef LN_LAUNCH_G
 #undef LN_LAUNCH
+#undef LN_LAUNCH_M
   VMG_LAUNCH_CHECK();
   return 0;
 }
