@@ -1,5 +1,6 @@
 """Which ops issue the full-size strided copies / adds / cats of a train step?  One profiled step (CPU activity, shapes); prints every aten::copy_ /
-aten::add / aten::add_ / aten::cat / aten::mul whose largest input has >= 4 M elements with its chain of enclosing ops.  python tools/big_copies.py"""
+aten::add / aten::add_ / aten::cat / aten::mul whose largest input has >= N elements (default 4 M; 0 lists every one, with aten::fill_ / zero_) with its chain of enclosing ops.
+python tools/big_copies.py [N]"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,9 +20,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     step(lrs, hrs)
     torch.cuda.synchronize()
+THRESH = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+NAMES = ("aten::copy_", "aten::add", "aten::add_", "aten::cat", "aten::mul", "aten::mul_") + (("aten::fill_", "aten::zero_") if THRESH == 0 else ())
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name not in ("aten::copy_", "aten::add", "aten::add_", "aten::cat", "aten::mul", "aten::mul_"):
+    if ev.name not in NAMES:
         continue
     shapes = [s for s in (ev.input_shapes or []) if s]
     big = 0
@@ -38,12 +41,12 @@ for ev in prof.events():
                     for v in t:
                         n *= v
                     big = max(big, n)
-    if big < 4_000_000:
+    if big < THRESH:
         continue
     chain, p = [], ev.cpu_parent
     while p is not None and len(chain) < 4:
         chain.append(p.name.replace("autograd::engine::evaluate_function: ", "")[:40])
         p = p.cpu_parent
-    cnt[(ev.name, " <- ".join(chain) or "-", str(shapes[0])[:40])] += 1
-for (name, chain, shp), c in cnt.most_common(40):
+    cnt[(ev.name, " <- ".join(chain) or "-", str(shapes[0] if shapes else "")[:40])] += 1
+for (name, chain, shp), c in cnt.most_common(40 if THRESH else 90):
     print("%4d  %-12s %-40s %s" % (c, name, shp, chain))

@@ -21,7 +21,8 @@ namespace {
 constexpr int MF_WAVES = 8;
 constexpr int MF_MAXK = 5;  // 16-byte vectors of ONE group's pixel block per lane: chunk * C/8 <= 320
 typedef __attribute__((ext_vector_type(4))) unsigned int mf_u32x4;  // (a native vector: the HIP uint4 struct behind a pointer select goes through scratch)
-__device__ __attribute__((aligned(16))) unsigned int g_mf_zero[4] = {0, 0, 0, 0};  // (not const: a constant-address-space pointer in the select turns the loads into flat_load)
+
+__device__ __attribute__((aligned(16))) unsigned int g_mf_trash[4];  // where the stores of lanes outside the image go
 
 struct MorphK {
   const bf16* x;      // (BT, H, W, C)
@@ -41,7 +42,9 @@ struct MorphK {
 
 // EVEN: S is even -- a lane's features come in pairs that never straddle a position, so the gather reads and the scatter writes 32 bits
 // at a time (half the LDS instructions and address arithmetic of the element-wise form; S = 18 in VMG-REDS-few_levels).
-template <int NK, int NCT, bool EVEN>
+// MASK: the data-gradient form (a.mask given) -- a template parameter: loads behind a run-time branch, even a wave-uniform one, are each
+// followed by s_waitcnt vmcnt(0).
+template <int NK, int NCT, bool EVEN, bool MASK>
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const MorphK a) {
   constexpr int COB = NCT * 16, KSB = 4 * COB * 16;  // bytes of one k-step of the pack
   constexpr int NST = (NK + 1) / 2;                  // stages (two k-steps each) of the pack
@@ -52,8 +55,11 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
   const int blkb = (16 * rowb + 15) & ~15;
   char* wl = smem;                                    // [NST][ss]
   float* lbias = reinterpret_cast<float*>(smem + NST * a.ss);  // [COB]
-  char* xblk = smem + NST * a.ss + COB * 4 + wave * 2 * blkb;  // [16 pixels][Cp] bf16
+  char* xblk = smem + NST * a.ss + COB * 4 + wave * (2 * blkb + 16);  // [16 pixels][Cp] bf16
   char* oblk = xblk + blkb;
+  // the wave's 16-byte tail: a ZERO word the gather reads for features >= Cp, and a TRASH word the scatter writes for them
+  const int zoff = 2 * blkb, toff = 2 * blkb + 4;
+  if (lane == 0) *reinterpret_cast<unsigned int*>(xblk + zoff) = 0u;
   // weights and bias -> LDS, once
   for (int i = tid * 16; i < NST * a.ss; i += MF_WAVES * 64 * 16) *reinterpret_cast<uint4*>(wl + i) = *reinterpret_cast<const uint4*>(a.wpack + i);
   for (int i = tid; i < COB; i += MF_WAVES * 64) lbias[i] = (a.bias && i < a.Cp) ? a.bias[i] : 0.f;
@@ -62,68 +68,108 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
   const int tok = lane & 15, kq = lane >> 4;
   const int ch = a.chunk, S = a.S;
   const int grp = tok / ch, kk = tok - grp * ch;  // this lane's token: group `grp` of the tile, channel chunk kk
-  // per k-step: (position, channel-in-chunk) of the first of the lane's 8 features
-  int p0[NK], s0[NK];
+  // LDS offsets (from xblk) of the lane's gather reads and scatter writes: they depend on the lane only, not on the tile.  Computed per
+  // tile -- position / channel by division and carry, a branch per element for the padding -- the tile body was ~3 000 instructions for
+  // 45 MFMAs and the kernel issue-bound at 2 TB/s (32 us per branch at N = 114 688); with the tables it is a few hundred.
+  constexpr int GE = EVEN ? 4 : 8;   // gather reads per k-step (32-bit pairs / single elements)
+  constexpr int SE = EVEN ? 2 : 4;   // scatter writes per output tile
+  int goff[NK][GE], soff[NCT][SE];
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
     const int f0 = 32 * ks + 8 * kq;
-    p0[ks] = f0 / S;
-    s0[ks] = f0 - p0[ks] * S;
+#pragma unroll
+    for (int j = 0; j < GE; ++j) {
+      const int f = f0 + (EVEN ? 2 * j : j);
+      const int p = f / S, sc = f - p * S;
+      goff[ks][j] = p < ch ? (grp * ch + p) * rowb + (kk * S + sc) * 2 : zoff;  // features >= Cp multiply zero weights
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+    for (int j = 0; j < SE; ++j) {
+      const int f = ct * 16 + kq * 4 + (EVEN ? 2 * j : j);
+      const int p = f / S, sc = f - p * S;
+      soff[ct][j] = f < a.Cp ? blkb + (grp * ch + p) * rowb + (kk * S + sc) * 2 : toff;  // (Cp even in the EVEN form: a pair is inside or outside together)
+    }
   }
   const int vpp = a.C >> 3;      // 16-byte vectors per pixel (C % 8 == 0)
   const int G = 16 / ch;         // groups per tile (1 or 2: the host admits chunk 8 and 16 here)
   const int lines_len = a.axis == 0 ? a.H : a.W, lines = a.axis == 0 ? a.W : a.H;
   const int pos_stride = a.axis == 0 ? a.W : 1;  // pixels between consecutive positions of a group
-  // per-lane constants of a group's copy: vector L = 64 k + lane of the [chunk pixels][vpp vectors] list (the same for every tile)
-  int lp[MF_MAXK], lv[MF_MAXK];
+  // per-lane constants of a group's copy: vector L = 64 k + lane of the [chunk pixels][vpp vectors] list (the same for every tile): its position
+  // in the group, its byte offset from the group's first pixel in the feature map and in the LDS block.  A group's address is then one
+  // wave-uniform 64-bit base + a 32-bit lane offset (the per-vector 64-bit products cost ~35 instructions per load before)
+  int lp[MF_MAXK], xoff[MF_MAXK], lxo[MF_MAXK];
 #pragma unroll
   for (int k = 0; k < MF_MAXK; ++k) {
     const int L = 64 * k + lane;
     const int p = (int)(((float)L + 0.5f) * (1.0f / (float)vpp));  // exact: L < 2^16
+    const int v = L - p * vpp;
     lp[k] = L < ch * vpp ? p : -1;
-    lv[k] = L - p * vpp;
+    xoff[k] = lp[k] >= 0 ? (p * pos_stride * a.C + v * 8) * 2 : 0;
+    lxo[k] = p * rowb + v * 16;
   }
-  const bf16* zsrc = reinterpret_cast<const bf16*>(g_mf_zero);
 
-  for (long long tile = (long long)blockIdx.x * MF_WAVES + wave; tile < a.ntiles; tile += (long long)gridDim.x * MF_WAVES) {
-    // ---- 1. pixel block -> LDS (zero-filled padding).  Group coordinates are wave-uniform; every load is UNCONDITIONAL (a lane outside
-    // the image reads the zero vector) and all of a tile's loads are issued before the first one is used: loads behind a per-lane branch
-    // are each followed by s_waitcnt vmcnt(0), which made a tile cost ten serialised memory latencies (46 us per launch at N = 114 688).
-    long long gbase[2];  // first pixel of the group, or -1
+  // ---- 1. pixel block -> LDS (zero-filled padding).  Group coordinates are wave-uniform; every load is UNCONDITIONAL (a lane outside the
+  // image reads the group's first vector and zeroes it in registers): loads behind a per-lane branch are each followed by s_waitcnt
+  // vmcnt(0), which made a tile cost ten serialised memory latencies (46 us per launch at N = 114 688).  (Tried: the loads of tile t+1
+  // issued before tile t is multiplied, registers carried around the loop -- 29.8 us against 25.5: hipcc's waits at the loop top cover
+  // the tile's stores as well.)  The stores are unconditional too: a lane outside the image writes a trash vector.
+  struct Geo {
+    long long gbyte[2];  // byte offset of the group's first pixel (0 for a group past the end)
+    bool glive[2];
     int gpos0[2];
+  };
+  auto geometry = [&](long long tile, Geo& ge) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const unsigned gg = (unsigned)(tile * G + g);  // (the host checks ngroups < 2^31)
       const unsigned gi = gg % (unsigned)a.gpl, r = gg / (unsigned)a.gpl;
       const unsigned line = r % (unsigned)lines, bt = r / (unsigned)lines;
-      gpos0[g] = (int)gi * ch;
-      const long long first = a.axis == 0 ? ((long long)bt * a.H + gpos0[g]) * a.W + line : ((long long)bt * a.H + line) * a.W + gpos0[g];
-      gbase[g] = (g < G && tile * G + g < a.ngroups) ? first : -1;
+      ge.gpos0[g] = (int)gi * ch;
+      const long long first = a.axis == 0 ? ((long long)bt * a.H + ge.gpos0[g]) * a.W + line : ((long long)bt * a.H + line) * a.W + ge.gpos0[g];
+      ge.glive[g] = g < G && tile < a.ntiles && tile * G + g < a.ngroups;
+      ge.gbyte[g] = ge.glive[g] ? first * a.C * 2 : 0;
     }
-    mf_u32x4 rx[2][MF_MAXK], rm[2][MF_MAXK];
+  };
+  auto issue = [&](const Geo& ge, mf_u32x4 (&vx)[2][MF_MAXK], mf_u32x4 (&vm)[2][MF_MAXK]) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      const char* gx = reinterpret_cast<const char*>(a.x) + ge.gbyte[g];
+      const char* gm = reinterpret_cast<const char*>(a.mask) + ge.gbyte[g];
 #pragma unroll
       for (int k = 0; k < MF_MAXK; ++k) {
-        const bool ok = lp[k] >= 0 && gbase[g] >= 0 && gpos0[g] + lp[k] < lines_len;
-        const long long off = (gbase[g] + (long long)lp[k] * pos_stride) * a.C + lv[k] * 8;
-        rx[g][k] = *reinterpret_cast<const mf_u32x4*>(ok ? a.x + off : zsrc);
-        if (a.mask) rm[g][k] = *reinterpret_cast<const mf_u32x4*>(ok ? a.mask + off : zsrc);  // (wave-uniform branch)
+        const bool okk = lp[k] >= 0 && ge.glive[g] && ge.gpos0[g] + lp[k] < lines_len;
+        const int o = okk ? xoff[k] : 0;
+        vx[g][k] = *reinterpret_cast<const mf_u32x4*>(gx + o);
+        if constexpr (MASK) vm[g][k] = *reinterpret_cast<const mf_u32x4*>(gm + o);
       }
     }
+  };
+  for (long long tile = (long long)blockIdx.x * MF_WAVES + wave; tile < a.ntiles; tile += (long long)gridDim.x * MF_WAVES) {
+    Geo gc;
+    mf_u32x4 rx[2][MF_MAXK], rm[2][MF_MAXK];
+    bool ok[2][MF_MAXK];
+    geometry(tile, gc);
+    issue(gc, rx, rm);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int k = 0; k < MF_MAXK; ++k) ok[g][k] = lp[k] >= 0 && gc.glive[g] && gc.gpos0[g] + lp[k] < lines_len;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
       for (int k = 0; k < MF_MAXK; ++k) {
-        mf_u32x4 val = rx[g][k];
-        if (a.mask) {
+        mf_u32x4 val = ok[g][k] ? rx[g][k] : mf_u32x4{0u, 0u, 0u, 0u};
+        if constexpr (MASK) {
           bf16x8 e = __builtin_bit_cast(bf16x8, val);
           const bf16x8 m = __builtin_bit_cast(bf16x8, rm[g][k]);
 #pragma unroll
           for (int j = 0; j < 8; ++j) e[j] = (float)m[j] > 0.f ? (bf16)((float)e[j] * a.in_scale) : (bf16)0.f;
           val = __builtin_bit_cast(mf_u32x4, e);
         }
-        if (lp[k] >= 0 && g < G) *reinterpret_cast<mf_u32x4*>(xblk + (g * ch + lp[k]) * rowb + lv[k] * 16) = val;
+        if (lp[k] >= 0 && g < G) *reinterpret_cast<mf_u32x4*>(xblk + g * ch * rowb + lxo[k]) = val;
       }
     }
     if (a.Cp > a.C) {  // padded channels read as zero
@@ -142,28 +188,21 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       bf16x8 tf;
-      int p = p0[ks], s = s0[ks];
       if constexpr (EVEN) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
         u32x4_t tw;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = p < ch;  // features >= Cp multiply zero weights
-          tw[j] = in ? *reinterpret_cast<const unsigned int*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : 0u;
-          s += 2;
-          if (s == S) { s = 0; ++p; }
-        }
+        for (int j = 0; j < 4; ++j) tw[j] = *reinterpret_cast<const unsigned int*>(xblk + goff[ks][j]);
         tf = __builtin_bit_cast(bf16x8, tw);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool in = p < ch;  // features >= Cp multiply zero weights
-          tf[j] = in ? *reinterpret_cast<const bf16*>(xblk + (grp * ch + p) * rowb + (kk * S + s) * 2) : (bf16)0.f;
-          if (++s == S) { s = 0; ++p; }
-        }
+        for (int j = 0; j < 8; ++j) tf[j] = *reinterpret_cast<const bf16*>(xblk + goff[ks][j]);
       }
       // the lane's fragment = features 32 ks + 8 kq .. + 7 of token (tile, tok): one 16-byte vector of the token matrix
-      if (a.tok_out && 32 * ks + 8 * kq < a.Cp) *reinterpret_cast<bf16x8*>(a.tok_out + (tile * 16 + tok) * a.Cp + 32 * ks + 8 * kq) = tf;
+      {  // (unconditional store, a trash vector for the lanes / launches without it: see above)
+        bf16* tp = (a.tok_out && 32 * ks + 8 * kq < a.Cp) ? a.tok_out + (tile * 16 + tok) * a.Cp + 32 * ks + 8 * kq : reinterpret_cast<bf16*>(g_mf_trash);
+        *reinterpret_cast<bf16x8*>(tp) = tf;
+      }
       const char* wk = wl + (ks >> 1) * a.ss + (ks & 1) * KSB + kq * (COB * 16) + tok * 16;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -174,40 +213,33 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
     // ---- 4. epilogue: lane holds output features f' = ct*16 + kq*4 + r of its token -> pixel (grp, p' = f'/S), channel kk*S + f'%S
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      const int f0 = ct * 16 + kq * 4;
-      int p = f0 / S, s = f0 - p * S;
-      if constexpr (EVEN) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(lbias + ct * 16 + kq * 4);
+      float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          if (f0 + r < a.Cp) {  // (Cp is even: the pair is inside or outside together)
-            float v0 = acc[ct][r] + lbias[f0 + r], v1 = acc[ct][r + 1] + lbias[f0 + r + 1];
-            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-            const bf16x2_t pr = {(bf16)(v0 * a.out_scale), (bf16)(v1 * a.out_scale)};
-            *reinterpret_cast<bf16x2_t*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = pr;
-          }
-          s += 2;
-          if (s == S) { s = 0; ++p; }
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[ct][r] + bv[r];
+        if (a.relu) v[r] = fmaxf(v[r], 0.f);
+        v[r] *= a.out_scale;
+      }
+      if constexpr (EVEN) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x2_t pr = {(bf16)v[2 * j], (bf16)v[2 * j + 1]};
+          *reinterpret_cast<bf16x2_t*>(xblk + soff[ct][j]) = pr;
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (f0 + r < a.Cp) {
-            float v = acc[ct][r] + lbias[f0 + r];
-            if (a.relu) v = fmaxf(v, 0.f);
-            *reinterpret_cast<bf16*>(oblk + (grp * ch + p) * rowb + (kk * S + s) * 2) = (bf16)(v * a.out_scale);
-          }
-          if (++s == S) { s = 0; ++p; }
-        }
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(xblk + soff[ct][r]) = (bf16)v[r];
       }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      char* go = reinterpret_cast<char*>(a.out) + gc.gbyte[g];
 #pragma unroll
       for (int k = 0; k < MF_MAXK; ++k) {
-        if (lp[k] < 0 || gbase[g] < 0 || gpos0[g] + lp[k] >= lines_len) continue;
-        const long long off = (gbase[g] + (long long)lp[k] * pos_stride) * a.C + lv[k] * 8;
-        *reinterpret_cast<mf_u32x4*>(a.out + off) = *reinterpret_cast<const mf_u32x4*>(oblk + (g * ch + lp[k]) * rowb + lv[k] * 16);
+        char* dst = ok[g][k] ? go + xoff[k] : reinterpret_cast<char*>(g_mf_trash);
+        *reinterpret_cast<mf_u32x4*>(dst) = *reinterpret_cast<const mf_u32x4*>(oblk + (lp[k] >= 0 ? g * ch * rowb + lxo[k] : 0));
       }
     }
   }
@@ -248,16 +280,16 @@ extern "C" int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* r
   k.relu = relu; k.in_scale = in_scale; k.out_scale = out_scale;
   k.ss = morph_stage_stride(nct);
   const int blkb = (16 * Cp * 2 + 15) & ~15;
-  const int lds = ((nk + 1) / 2) * k.ss + nct * 16 * 4 + MF_WAVES * 2 * blkb;
+  const int lds = ((nk + 1) / 2) * k.ss + nct * 16 * 4 + MF_WAVES * (2 * blkb + 16);
   VMG_CHECK(lds <= 160 * 1024, "morphfc: Cp = %d needs %d B of LDS (> 160 KiB): use the unfused path", Cp, lds);
   hipStream_t st = (hipStream_t)stream;
   const int ncu = vmg_cu_count(vmg_current_device());
   long long nwg = cdiv64(k.ntiles, MF_WAVES);
   if (nwg > ncu) nwg = ncu;  // one workgroup per CU (the LDS holds the weights): tiles are strided over the waves
-#define MF_CASE(NK_, NCT_) MF_CASE2(NK_, NCT_, true) MF_CASE2(NK_, NCT_, false)
-#define MF_CASE2(NK_, NCT_, EV_)                                                                                    \
-  if (nk == NK_ && nct == NCT_ && (k.S % 2 == 0) == EV_) {                                                          \
-    auto fn = morph_linear_kernel<NK_, NCT_, EV_>;                                                                  \
+#define MF_CASE(NK_, NCT_) MF_CASE2(NK_, NCT_, true, true) MF_CASE2(NK_, NCT_, false, true) MF_CASE2(NK_, NCT_, true, false) MF_CASE2(NK_, NCT_, false, false)
+#define MF_CASE2(NK_, NCT_, EV_, MK_)                                                                               \
+  if (nk == NK_ && nct == NCT_ && (k.S % 2 == 0) == EV_ && (relu_mask != nullptr) == MK_) {                         \
+    auto fn = morph_linear_kernel<NK_, NCT_, EV_, MK_>;                                                             \
     static bool attr_set[VMG_MAX_DEVICES] = {};                                                                     \
     const int dev = vmg_current_device();                                                                           \
     if (!attr_set[dev]) {                                                                                           \
