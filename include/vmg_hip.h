@@ -233,6 +233,10 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
  * vmg_pixel_unshuffle_actgrad  the backward of "conv -> PixelShuffle(2) -> activation" in front of the conv's gradients, one pass:
  *                    out[n,y,x,4c+2i+j] = dy[n,2y+i,2x+j,c] * alpha * act'(ref[n,2y+i,2x+j,c]); dy / ref (N,2H,2W,c), out (N,H,W,4c);
  *                    ref = null with VMG_ACT_NONE.  c a multiple of the 16-byte vector (8 bf16 / 4 fp32).  models/vmg.py:629-630.
+ * vmg_frame_gather   dst frame f = sum_{k < nsrc} src frame idx[f*nsrc + k] (nsrc 1 or 2; idx: device int32, < 0 = no term; fp32 sum, one
+ *                    rounding); frames = contiguous blocks of frame_elems elements (whole 16-byte vectors).  The two direction sweeps of
+ *                    the recurrence (models/trajectory.py:323-392, 407-477) run as one batch: step j works on [frame t-1-j | frame j] of
+ *                    every clip -- that arrangement of the (n, t) features is one gather, its gradient one gather-add.
  * vmg_layernorm_fwd  y = (x - mean) * rstd * w + b over the last dim C of (M, C) rows, eps inside the sqrt; mean / rstd
  *                    (fp32, M each) are written when non-null.  nn.LayerNorm at function.py:1164,1195; layers.py:768-775;
  *                    swin_3d.py:717,741.
@@ -241,6 +245,8 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
 int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
                 void* stream);
 int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream);
+int vmg_frame_gather(int dtype, const void* src, void* dst, const int* idx, int64_t frame_elems, int n_src_frames, int n_dst_frames, int nsrc,
+                     void* stream);
 int vmg_pixel_unshuffle_actgrad(int dtype, const void* dy, const void* ref, void* out, int N, int H, int W, int c, int act, float slope,
                                 float alpha, void* stream);
 int vmg_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t M,

@@ -143,3 +143,26 @@ def test_flow_warp_backward_with_many_clamped_pixels_bf16_vs_fp32():
     # and two bf16 runs agree to the fp32 sum's arrival-order rounding
     g16b, _ = run(torch.bfloat16)
     assert float(((g16 - g16b).abs() / (g16.abs() + 1e-3)).max()) <= 2 ** -7
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,t", [(1, 1), (2, 5), (3, 7)])
+def test_pair_frames_is_transpose_flip_cat_and_its_gradient(dtype, n, t):
+    """functional.pair_frames (vmg_frame_gather): the (t, 2n) arrangement the lock-step sweeps work on = cat([flip(x^T), x^T], 1), bit-exact;
+    its gradient = the autograd gradient of that torch expression (two terms per element, fp32 sum: bit-exact in fp32, one rounding in bf16)."""
+    from vmg_amd import functional as FH
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((n, t, 6, 5, 16), generator=g, device="cuda").to(dtype).requires_grad_(True)
+    got = FH.pair_frames(x)
+    xt = x.detach().clone().requires_grad_(True)
+    xtt = xt.transpose(0, 1)
+    want = torch.cat([xtt.flip(0), xtt], 1)
+    assert got.shape == want.shape and torch.equal(got, want)
+    go = torch.randn(want.shape, generator=g, device="cuda").to(dtype)
+    got.backward(go)
+    want.float().backward(go.float()) if dtype == torch.float32 else want.backward(go)
+    if dtype == torch.float32:
+        assert torch.equal(x.grad, xt.grad)
+    else:
+        ref = (go.float()[:, :n].flip(0) + go.float()[:, n:]).transpose(0, 1)  # the exact sum, rounded once
+        assert torch.equal(x.grad, ref.to(dtype))

@@ -500,6 +500,44 @@ int ln_group(int nvec) {
   return best;
 }
 
+
+// ----------------------------------------------------------------------------------------- frame gather
+// dst frame f = sum over k < nsrc of src frame idx[f * nsrc + k] (an index < 0 is skipped), frames = contiguous blocks of `fv` 16-byte
+// vectors.  The recurrence (model.py: Trajectory_multi_head) runs its two direction sweeps as one batch: step j works on
+// [frame t-1-j | frame j] of every clip.  That (t, 2n) arrangement is ONE gather from the batch-major (n, t) features (nsrc = 1) and its
+// gradient ONE gather-add (nsrc = 2, fp32 sum, one rounding) -- torch spelled it transpose + flip + cat, three passes each way.
+template <typename T, int NSRC>
+__global__ __launch_bounds__(256) void frame_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ idx, long long fv,
+                                                           int chunks) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  typedef VecN<T, VN> Vec;
+  const int f = blockIdx.x / chunks, ck = blockIdx.x - f * chunks;
+  int s[NSRC];
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) s[k] = idx[f * NSRC + k];
+  const long long v0 = fv * ck / chunks, v1 = fv * (ck + 1) / chunks;
+  Vec* d = reinterpret_cast<Vec*>(dst) + (long long)f * fv;
+  for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
+    if (NSRC == 1) {
+      d[v] = reinterpret_cast<const Vec*>(src)[(long long)s[0] * fv + v];  // (the host rejects a negative index when nsrc = 1)
+    } else {
+      float acc[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NSRC; ++k) {
+        const Vec a = reinterpret_cast<const Vec*>(src)[(long long)(s[k] < 0 ? 0 : s[k]) * fv + v];
+        const float keep = s[k] < 0 ? 0.f : 1.f;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] += to_f32(a.v[e]) * keep;
+      }
+      Vec o;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) o.v[e] = from_f32<T>(acc[e]);
+      d[v] = o;
+    }
+  }
+}
 }  // namespace
 
 extern "C" int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
@@ -514,6 +552,27 @@ extern "C" int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out
   else
     hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)ref,
                        (float*)out, (long long)n, act, slope, alpha);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_frame_gather(int dtype, const void* src, void* dst, const int* idx, int64_t frame_elems, int n_src_frames, int n_dst_frames, int nsrc,
+                                void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "frame_gather: bad dtype");
+  VMG_CHECK(src && dst && idx && frame_elems > 0 && n_src_frames > 0 && n_dst_frames > 0 && (nsrc == 1 || nsrc == 2), "frame_gather: bad arguments (nsrc 1 or 2)");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(frame_elems % vn == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "frame_gather: frames must be whole 16-byte vectors, tensors 16-byte aligned");
+  (void)n_src_frames;  // (the index table lives on the device: the caller guarantees idx < n_src_frames; see kernels.frame_gather)
+  const long long fv = frame_elems / vn;
+  long long chunks = cdiv64(2048, n_dst_frames);  // ~2 048 blocks in all
+  if (chunks > cdiv64(fv, 256)) chunks = cdiv64(fv, 256);
+  if (chunks < 1) chunks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(n_dst_frames * chunks));
+#define FG_LAUNCH(T, NS) hipLaunchKernelGGL((frame_gather_kernel<T, NS>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, idx, fv, (int)chunks)
+  if (dtype == VMG_BF16) { if (nsrc == 1) FG_LAUNCH(bf16, 1); else FG_LAUNCH(bf16, 2); }
+  else { if (nsrc == 1) FG_LAUNCH(float, 1); else FG_LAUNCH(float, 2); }
+#undef FG_LAUNCH
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -1013,6 +1013,42 @@ def split_halves(x: torch.Tensor):
     return _SplitHalves.apply(x)
 
 
+_PAIR_INDEX = {}
+
+
+def _pair_index(n: int, t: int, device):
+    """index tables of pair_frames: forward (t * 2n, 1) into the (n, t) frames, backward (n * t, 2) into the (t, 2n) frames."""
+    key = (n, t, str(device))
+    tabs = _PAIR_INDEX.get(key)
+    if tabs is None:
+        fwd = [[r * t + (t - 1 - j)] if r < n else [(r - n) * t + j] for j in range(t) for r in range(2 * n)]
+        bwd = [[(t - 1 - i) * 2 * n + b, i * 2 * n + n + b] for b in range(n) for i in range(t)]
+        tabs = _PAIR_INDEX[key] = (torch.tensor(fwd, dtype=torch.int32, device=device), torch.tensor(bwd, dtype=torch.int32, device=device))
+    return tabs
+
+
+class _PairFrames(_Fn):
+    @staticmethod
+    def forward(ctx, x):
+        n, t = x.shape[:2]
+        ctx.n, ctx.t, ctx.frame = n, t, tuple(x.shape[2:])
+        fi, _ = _pair_index(n, t, x.device)
+        return K.frame_gather(x.contiguous(), fi, 2 * n * t, ctx.frame).view(t, 2 * n, *ctx.frame)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, t = ctx.n, ctx.t
+        _, bi = _pair_index(n, t, g.device)
+        return K.frame_gather(g.contiguous(), bi, n * t, ctx.frame).view(n, t, *ctx.frame)
+
+
+def pair_frames(x: torch.Tensor) -> torch.Tensor:
+    """x (n, t, ...) batch-major -> (t, 2n, ...): row j = [frame t-1-j of every clip | frame j of every clip] -- what step j of the two
+    direction sweeps of the recurrence works on (model.Trajectory_multi_head).  One gather; the gradient is one gather-add
+    (dx[b, i] = g[t-1-i, b] + g[i, n+b], fp32 sum).  torch spells it transpose + flip + cat: three passes each way."""
+    return _PairFrames.apply(x)
+
+
 def morph_tokens(x: torch.Tensor, axis: str, chunk: int, Cp: int) -> torch.Tensor:
     """Token layout of the H-/W-branch (models/function.py:763-764, 776-777): pad C->Cp and the mixed axis to a
     multiple of `chunk`; token (group, k) gets features f = p*S + s <- x[position p of the group, channel k*S + s]."""

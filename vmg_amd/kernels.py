@@ -333,6 +333,22 @@ def pixel_shuffle(x: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def frame_gather(src: torch.Tensor, idx: torch.Tensor, n_dst: int, frame_shape) -> torch.Tensor:
+    """dst frame f = sum_k src frame idx[f, k] (vmg_frame_gather): src contiguous, its leading dims flattened into frames of prod(frame_shape)
+    elements; idx (n_dst, 1 or 2) int32 on the device, every entry < number of source frames (the CALLER's contract: the table is device data),
+    < 0 = no term.  Returns (n_dst, *frame_shape)."""
+    hip.require_cuda(src, idx)
+    fe = 1
+    for d in frame_shape:
+        fe *= int(d)
+    if not src.is_contiguous() or src.numel() % fe or idx.dtype != torch.int32 or idx.dim() != 2 or idx.shape[0] != n_dst or idx.shape[1] not in (1, 2) or not idx.is_contiguous():
+        raise HipError("frame_gather: contiguous src of whole frames and a contiguous int32 (n_dst, 1|2) index table expected")
+    dst = torch.empty((n_dst, *frame_shape), dtype=src.dtype, device=src.device)
+    hip.check(hip.lib().vmg_frame_gather(hip.dtype_code(src.dtype), src.data_ptr(), dst.data_ptr(), idx.data_ptr(), fe, src.numel() // fe, n_dst, idx.shape[1],
+                                         hip.stream_ptr()), "vmg_frame_gather")
+    return dst
+
+
 def pixel_unshuffle_actgrad(dy: torch.Tensor, ref: Optional[torch.Tensor], N: int, H: int, W: int, act: int, slope: float, alpha: float) -> torch.Tensor:
     """(N,2H,2W,c) gradient (and activation reference) -> (N,H,W,4c) pre-activation gradient of a PixelShuffle conv, one pass."""
     hip.require_cuda(dy, ref)

@@ -368,14 +368,13 @@ class Trajectory_multi_head(nn.Module):
         frames -- rows [0, n) are the backward sweep at frame t-1-j, rows [n, 2n) the forward sweep at frame j -- which
         doubles the pixels per launch of every kernel of the recurrence (M = 2*n*h*w) and halves the launch count."""
         n, t, h, w, c = x.shape
-        xt = x.transpose(0, 1).contiguous()  # time-major: every frame batch xt[i] is a dense (n,h,w,c) pixel array
         fb = flows_backward.permute(1, 0, 3, 4, 2).float()
         ff = flows_forward.permute(1, 0, 3, 4, 2).float()
         s = self.keyframe_stride
-        xpair = torch.cat([xt.flip(0), xt], 1)  # (t, 2n, h, w, c): step j -> [frame t-1-j | frame j]
+        xpair = FH.pair_frames(x)  # (t, 2n, h, w, c): step j -> [frame t-1-j | frame j], one gather from the batch-major features
         # step j >= 1 warps by flows_backward[:, t-1-j] (backward sweep) and flows_forward[:, j-1] (forward sweep)
         flpair = torch.cat([fb.flip(0), ff], 1).contiguous() if t > 1 else None  # (t-1, 2n, h, w, 2); row j-1 serves step j
-        ident = FH.identity_grid(2 * n, h, w, xt.device)
+        ident = FH.identity_grid(2 * n, h, w, x.device)
         loc = ident
         feat = None
         k_in: List[torch.Tensor] = []
@@ -402,10 +401,11 @@ class Trajectory_multi_head(nn.Module):
                 k_in.append(FH.grad_bank(cur))
             feats.append(feat)
         halves = [f.split(n, 0) for f in feats]  # step j: (backward sweep at frame t-1-j, forward sweep at frame j)
-        back = torch.stack([hv[0] for hv in reversed(halves)], 0)  # (t, n, h, w, c), frame order
-        fwd = torch.stack([hv[1] for hv in halves], 0)
-        out = conv(self.fusion, [back, xt, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
-        return out.reshape(t, n, h, w, c).transpose(0, 1).contiguous()
+        # the fusion is a 1x1 conv: its pixels may come in any order -- batch-major like x, so neither x nor the result is transposed
+        back = torch.stack([hv[0] for hv in reversed(halves)], 1)  # (n, t, h, w, c), frame order
+        fwd = torch.stack([hv[1] for hv in halves], 1)
+        out = conv(self.fusion, [back, x, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
+        return out.reshape(n, t, h, w, c)
 
 
 # ---------------------------------------------------------------------------------------------------------
