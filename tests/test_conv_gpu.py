@@ -363,6 +363,40 @@ def test_linear_wave_autonomous_variant(shape, tiles):
     _cmp(got.reshape(M, Co), F.relu(F.linear(_q(x, dtype), _q(w, dtype))) / Ci, dtype, f"wave-autonomous linear relu/scale {shape}")
 
 
+@pytest.mark.parametrize("case", [(2, 40, 52, 64, 64), (1, 8, 16, 64, 64), (3, 19, 37, 64, 64), (1, 64, 300, 8, 64), (2, 33, 20, 32, 48), (1, 24, 48, 48, 16),
+                                  (5, 128, 128, 64, 64), (1, 7, 5, 64, 16)])
+def test_conv_weights_stationary_variant(case):
+    """The weights-stationary 3x3 kernel (deep=6, conv_wstat_kernel: the layer's weights resident in LDS, a persistent workgroup per CU walks
+    over 8 x 16-pixel tiles, halo tiles double-buffered by a loader wave) against the oracle conv: ragged H / W (partial tiles at both
+    borders), fewer tiles than workgroups, more tiles than workgroups (several per workgroup, both halo buffers), 8..64 input channels, 16..64
+    output channels, every 16-byte epilogue.  Results must be identical run to run and identical to the general kernel's."""
+    hip, K, O, R = _setup()
+    dtype = torch.bfloat16
+    N, H, W, Ci, Co = case
+    x = R.seeded((N, H, W, Ci), 91)
+    w = R.seeded((Co, Ci, 3, 3), 92, (Ci * 9) ** -0.5)
+    b = R.seeded((Co,), 93, 0.1)
+    pre = O.conv_nhwc(_q(x, dtype), _q(w, dtype), b, 1)
+    pw = K.pack_conv_weight(w.cuda(), dtype, cout_tiles=Co // 16)
+    xd = x.cuda().to(dtype)
+    got, _ = K.conv_forward([xd], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1, deep=6)
+    _cmp(got, F.leaky_relu(pre, 0.1), dtype, f"weights-stationary conv lrelu {case}")
+    gen, _ = K.conv_forward([xd], pw, b.cuda(), N, H, W, act=hip.ACT_LRELU, slope=0.1, deep=0)
+    assert torch.equal(got, gen), "the weights-stationary kernel must give the general kernel's bits"
+    aux, res = R.seeded((N, H, W, Co), 94), R.seeded((N, H, W, Co), 95)
+    want = _q(res, dtype) + 0.5 * pre * (_q(aux, dtype) > 0).float()
+    kw = dict(alpha=0.5, res=res.cuda().to(dtype), aux=aux.cuda().to(dtype), actgrad=1, deep=6)
+    got, _ = K.conv_forward([xd], pw, b.cuda(), N, H, W, **kw)
+    _cmp(got, want, dtype, f"weights-stationary conv mask+residual {case}")
+    for _ in range(3):
+        again, _ = K.conv_forward([xd], pw, b.cuda(), N, H, W, **kw)
+        assert torch.equal(got, again)
+    got, got_pre = K.conv_forward([xd], pw, None, N, H, W, act=hip.ACT_GELU, want_pre=True, deep=6)
+    pre0 = O.conv_nhwc(_q(x, dtype), _q(w, dtype), None, 1)
+    _cmp(got_pre, pre0, dtype, f"weights-stationary conv pre {case}")
+    _cmp(got, F.gelu(pre0), dtype, f"weights-stationary conv gelu {case}")
+
+
 # ---------------------------------------------------------------------------------------------- weight-streaming kernel
 @pytest.mark.parametrize("shape", [(2, 24, 20, 144, 144), (8, 64, 64, 144, 144), (3, 9, 17, 128, 144), (1, 16, 16, 144, 288), (1, 8, 8, 112, 224),
                                    (2, 20, 33, 224, 112), (1, 12, 16, 448, 112), (1, 30, 50, 32, 144)])

@@ -109,6 +109,7 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& w, const Frag<float>& x,
 }
 
 __device__ uint4 g_conv_zero16;  // 16 zero bytes: the source of out-of-image lanes of the halo copy
+__device__ uint4 g_wstat_trash;  // where conv_wstat_kernel's items outside the image store (their stores stay unconditional: counted waits)
 
 // diagnostics: wave-level time stamps (100 MHz constant clock) at phase boundaries of the k-split kernel
 // (compiled in only with -DVMG_DIAG: tools/conv_timeline.py, tools/conv_ablate.py; the shipped library carries neither the
@@ -146,6 +147,14 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, char* lds_dst) {
   const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+}
+
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit lane offset: no per-lane 64-bit address arithmetic
+__device__ __forceinline__ void glds16_asm_s(const char* sbase, int voff, char* lds_dst) {
+  unsigned keep;
+  const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
 }
 
 template <typename T, int KS, int MT>
@@ -890,6 +899,276 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void linear_wres_kernel(const
   }
 }
 
+// ================================================================================================ weights-stationary 3x3 (few channels, many pixels)
+// The HR head (HRconv 64 -> 64 and conv_last's data gradient 8 -> 64 on 28 x 256 x 256 = 1.8 M pixels; models/vmg.py:629-632) on the general
+// kernel: 28 672 workgroups of 64 pixels, each streaming the layer's 74 KiB of weights through its LDS ring -- 2.1 GB of L2 -> LDS traffic for
+// 470 MB of activations, ~400 us per launch (1.2 TB/s, 13 % of the matrix roof).  Here the weights never move: ONE workgroup per CU keeps the
+// whole packed weight block of its output-channel block in LDS and walks over 128-pixel tiles (8 rows x 16 columns, like conv_ws_kernel).
+// Eight waves with fixed roles:
+//   * waves 0..3, the CONSUMERS, multiply tile t: wave w owns pixel rows 2w, 2w+1 x all NCT channel tiles.  The weight fragments of the first
+//     RW = min(NCT, 2) channel tiles of EVERY k-step live in the wave's registers (144 VGPRs at 64 -> 64), the others are read from LDS: per
+//     k-step 2 activation + (NCT - RW) weight reads for 2 NCT MFMAs.  (All weight fragments from LDS -- the same 4 KiB read by four waves
+//     per k-step -- made the loop LDS-bound: 2.9 us per tile for 1.2 us of MFMAs.)  A finished tile goes to an LDS patch [128 px][COB fp32];
+//   * waves 4..7 are HELPERS, one per SIMD beside a consumer.  Each copies a quarter of the halo tile of tile t+1 (10 x 18 pixels x <= 64
+//     channels, LDS pixel stride 144 bytes = 8 chunks + 1 pad for conflict-free 16-byte reads) by LDS-DMA into the second of two halo
+//     buffers, and turns a quarter of the patch of tile t-1 into (pixel, 8 channels) items -- bias, activation, mask, residual: every
+//     epilogue option of the general kernel, 16-byte stores, NCT items per lane -- while the consumers multiply tile t (the epilogue on the
+//     consumers cost 2 us per tile; on three store waves beside one loader 2.5 us);
+//   * two workgroup barriers per tile: X_t "halo t has landed, patch t-1 is written, the other halo buffer is free" and Y_t "patch t-1 is
+//     drained" (before the consumers overwrite it).
+// Tiles are dealt to the XCDs in contiguous bands (workgroup b belongs to XCD b % 8), so that the halo overlap of neighbouring tiles is read
+// through one L2.  HBM-bound: (23 KiB in + 16 KiB out) per tile.
+// FULL = false: the epilogue is bias + ReLU / LeakyReLU / none + scale only (what the HR head uses); the full item code (GELU, mask, residual,
+// pre-activation output) is ~5 000 instructions that the helpers have to branch around.
+template <int NCT, int NB, bool FULL>
+__global__ __launch_bounds__(512, 1) void conv_wstat_kernel(const ConvK a, int ntiles) {
+  using T = bf16;
+  constexpr int KS = 3, CB = 16, TH = 8, TWH = 18, THH = 10;
+  constexpr int COB = NCT * 16, KSB = 4 * COB * CB;
+  constexpr int SS = stage_stride(KS, NCT, CB);  // a stage of the pack = the three taps of one (channel block, tap row)
+  constexpr int NK = 9 * NB, RW = NCT < 2 ? NCT : 2;
+  constexpr int PIXB = 144;
+  constexpr int HVEC = THH * TWH * 9, NDMA = (HVEC + 63) / 64, HB = NDMA * 1024;
+  constexpr int PSTR = COB * 4 + 16, C8 = 2 * NCT, NITEM = 128 * C8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  const int CH = a.src_ch[0] >> 3;
+  constexpr int wbytes = 3 * NB * SS;
+  char* wl = smem;
+  char* halo = smem + wbytes;                                // [2][HB]
+  float* lbias = reinterpret_cast<float*>(halo + 2 * HB);   // [COB]
+  char* patch = halo + 2 * HB + COB * 4;                     // [128][PSTR]
+
+  // ---- the tiles of this workgroup: XCD band, then strided over the band's workgroups
+  const int per_xcd = gridDim.x >> 3;  // (the host launches a multiple of 8 workgroups)
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int band = (ntiles + 7) >> 3;
+  const int band0 = xcd * band, band1 = min(ntiles, band0 + band);
+  auto tile_of = [&](int it) { return band0 + it * per_xcd + local; };  // < band1 while the workgroup has work
+  auto barrier = [&]() {  // a bare barrier behind an LDS wait: __syncthreads() would also wait for the store waves' global stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // ---- prologue: the weight block and the bias -> LDS (all waves)
+  {
+    const char* wblk = a.wpack + (long long)cb * wbytes;
+    for (int i = tid * 16; i < wbytes; i += 512 * 16) *reinterpret_cast<uint4*>(wl + i) = *reinterpret_cast<const uint4*>(wblk + i);
+    for (int i = tid; i < COB; i += 512) lbias[i] = (a.bias && cb * COB + i < a.Cout) ? a.bias[cb * COB + i] : 0.f;
+  }
+
+  if (wave >= 4) {
+    // ================================================================ helpers: quarter of the halo copy + quarter of the previous tile's items
+    const int h = wave - 4;
+    // copy: vector v = 64 i + lane of the halo image [THH*TWH pixels][9 slots], helper h takes instructions i = h, h + 4, ...
+    constexpr int NDH = (NDMA + 3) / 4;
+    int lpos[NDH], loff[NDH];
+    const long long ps_b = a.src_ps[0] * 2;
+#pragma unroll
+    for (int k = 0; k < NDH; ++k) {
+      const int v = 64 * (h + 4 * k) + lane;
+      const int p = v / 9, c = v - p * 9;
+      const int hy = p / TWH, hx = p - hy * TWH;
+      lpos[k] = (v < HVEC && c < CH) ? (hy << 8) | hx : -1;
+      loff[k] = (hy * a.W + hx) * (int)ps_b + c * 16;
+    }
+    int lfast[NDH];  // the offsets of the fast path: a slot nobody reads (pad slot, chunk >= CH, past the tile) copies the tile's first vector
+#pragma unroll
+    for (int k = 0; k < NDH; ++k) lfast[k] = lpos[k] >= 0 ? loff[k] : 0;
+    auto issue_halo = [&](int t, int buf) {
+      const int tx = t % a.tiles_x, r = t / a.tiles_x;
+      const int ty = r % a.tiles_y, n = r / a.tiles_y;
+      const int y0 = ty * TH - 1, x0 = tx * 16 - 1;
+      const char* origin = a.src[0] + (((long long)n * a.H + y0) * a.W + x0) * ps_b;  // (may lie before the tensor: only in-image lanes use it)
+      char* dst = halo + buf * HB;
+      if (VMG_DBG(a, 1)) return;  // (ablation bits of the diagnostics build: 1 no halo copies, 32 no K loop, 64 no epilogue)
+      if (y0 >= 0 && x0 >= 0 && y0 + THH <= a.H && x0 + TWH <= a.W) {  // the whole halo tile inside the image (wave-uniform): base + lane offset
+#pragma unroll
+        for (int k = 0; k < NDH; ++k) {
+          if (h + 4 * k >= NDMA) break;  // (wave-uniform)
+          glds16_asm_s(origin, lfast[k], dst + (h + 4 * k) * 1024);
+        }
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < NDH; ++k) {
+        if (h + 4 * k >= NDMA) break;  // (wave-uniform)
+        const bool ok = lpos[k] >= 0 && (unsigned)(y0 + (lpos[k] >> 8)) < (unsigned)a.H && (unsigned)(x0 + (lpos[k] & 255)) < (unsigned)a.W;
+        const char* gp = ok ? origin + loff[k] : reinterpret_cast<const char*>(&g_conv_zero16);
+        glds16_asm(gp, dst + (h + 4 * k) * 1024);
+      }
+    };
+    // items: item j = 64 h + lane + 256 i of the [128 pixels][C8] list, i < NCT -- pixel, channel group, patch and output offsets do not
+    // depend on the tile
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    bf16* out_pre = FULL ? reinterpret_cast<bf16*>(a.out_pre) : nullptr;
+    const bf16* res = FULL ? reinterpret_cast<const bf16*>(a.res) : nullptr;
+    const bf16* aux = FULL ? reinterpret_cast<const bf16*>(a.aux) : nullptr;
+    const float neg = a.act == VMG_ACT_RELU ? 0.f : (a.act == VMG_ACT_LRELU ? a.slope : 1.f);
+    int ipos[NCT], ipatch[NCT], ico[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) {
+      const int j = 64 * h + lane + 256 * i;
+      const int p = j / C8, c8 = j - p * C8;
+      ipos[i] = ((p >> 4) << 8) | (p & 15);
+      ipatch[i] = p * PSTR + c8 * 32;
+      ico[i] = c8 * 8;
+    }
+    const int nstore = NCT * (out_pre ? 2 : 1);  // global stores a helper issues per tile, all of them unconditional (see below)
+    // the fast path of the simple epilogue on a tile that lies inside the image: byte offset of the item from the tile's first output vector,
+    // the bias of the item's 8 channels in registers
+    int ioff[NCT];
+    float ibias[NCT][8];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) {
+      ioff[i] = (((ipos[i] >> 8) * a.W + (ipos[i] & 255)) * (int)a.out_ps + ico[i]) * 2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ibias[i][q] = (a.bias && cb * COB + ico[i] + q < a.Cout) ? a.bias[cb * COB + ico[i] + q] : 0.f;
+    }
+
+    if (tile_of(0) < band1) issue_halo(tile_of(0), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int it = 0;; ++it) {
+      barrier();  // X_it: halo it has landed, patch it-1 is written (after the last tile: the drain's X)
+      const bool more = tile_of(it) < band1;
+      if (more && tile_of(it + 1) < band1) issue_halo(tile_of(it + 1), (it + 1) & 1);
+      if (it > 0 && !VMG_DBG(a, 64)) {
+        const int t = tile_of(it - 1);
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        const int ty = r % a.tiles_y, n = r / a.tiles_y;
+        const long long pix0 = ((long long)n * a.H + ty * TH) * a.W + tx * 16;
+        if (!FULL && ty * TH + TH <= a.H && tx * 16 + 16 <= a.W && cb * COB + COB <= a.Cout && !VMG_DBG(a, 8)) {  // (wave-uniform)
+          char* obase = reinterpret_cast<char*>(out + pix0 * a.out_ps + cb * COB);
+#pragma unroll
+          for (int i = 0; i < NCT; ++i) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + ipatch[i]);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + ipatch[i] + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16x8 tq;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              if (a.bias) v[q] += ibias[i][q];
+              v[q] = (v[q] > 0.f ? v[q] : v[q] * neg) * a.alpha;  // (the same operations as below)
+              tq[q] = (bf16)v[q];
+            }
+            *reinterpret_cast<bf16x8*>(obase + ioff[i]) = tq;
+          }
+        } else
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+          const int y = ty * TH + (ipos[i] >> 8), x = tx * 16 + (ipos[i] & 255);
+          const int co = cb * COB + ico[i];
+          const bool valid = y < a.H && x < a.W && co < a.Cout && !VMG_DBG(a, 8);
+          const long long pix = valid ? pix0 + (long long)(ipos[i] >> 8) * a.W + (ipos[i] & 255) : 0;  // (an item outside the image reads pixel 0 and stores to a trash vector)
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + ipatch[i]);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + ipatch[i] + 16);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          // (the item arithmetic of conv_epilogue_lds8, operation for operation: both kernels give the same bits)
+          if (a.bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lbias + ico[i]), b1 = *reinterpret_cast<const f32x4*>(lbias + ico[i] + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+          }
+          const int cov = valid ? co : 0;
+          if (out_pre) {
+            bf16x8 tq;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tq[q] = (bf16)v[q];
+            bf16* dstp = valid ? out_pre + pix * a.out_ps + co : reinterpret_cast<bf16*>(&g_wstat_trash);
+            *reinterpret_cast<bf16x8*>(dstp) = tq;
+          }
+          if (FULL && a.act == VMG_ACT_GELU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]) * a.alpha;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (v[q] > 0.f ? v[q] : v[q] * neg) * a.alpha;
+          }
+          if (aux) {
+            const bf16x8 au = *reinterpret_cast<const bf16x8*>(aux + pix * a.aux_ps + cov);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float u = (float)au[q];
+              v[q] *= a.actgrad == 3 ? gelu_erf_grad(u) : (u > 0.f ? 1.f : (a.actgrad == 2 ? a.slope : 0.f));
+            }
+          }
+          if (res) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + pix * a.res_ps + cov);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+          }
+          bf16x8 tq;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tq[q] = (bf16)v[q];
+          bf16* dst = valid ? out + pix * a.out_ps + co : reinterpret_cast<bf16*>(&g_wstat_trash);
+          *reinterpret_cast<bf16x8*>(dst) = tq;
+        }
+      }
+      if (!more) break;
+      barrier();  // Y_it: patch it-1 is drained
+      // the halo copy must have landed before X_{it+1}; it is OLDER than this tile's stores, which may stay in flight: a counted wait
+      if (it > 0 && !VMG_DBG(a, 64)) {
+        if (nstore == NCT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCT) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    return;
+  }
+
+  // ================================================================ consumers
+  barrier();  // X_0 (the weights are in LDS, the first halo tile has landed)
+  // the register-resident weight fragments: channel tiles 0..RW-1 of every k-step
+  Frag<T> wreg[NK][RW];
+  const char* wlane = wl + g * (COB * CB) + px * CB;
+#pragma unroll
+  for (int j = 0; j < NK; ++j)
+#pragma unroll
+    for (int ct = 0; ct < RW; ++ct) wreg[j][ct].load(wlane + (j / 3) * SS + (j % 3) * KSB + ct * 16 * CB);
+  for (int it = 0;; ++it) {
+    const int t = tile_of(it);
+    if (t >= band1) break;  // (workgroup-uniform; the other roles leave at the same X)
+    const int buf = it & 1;
+    f32x4 acc[2][NCT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* hb = halo + buf * HB + ((2 * wave) * TWH + px) * PIXB;
+    if (!VMG_DBG(a, 32)) {
+      Frag<T> xf[2][2], wf[2][NCT > RW ? NCT - RW : 1];
+      auto load_frags = [&](int j, int set) {
+        const int cbk = j / 9, tap = j - cbk * 9, ky = tap / 3, kx = tap - ky * 3;
+        const char* xc = hb + min(4 * cbk + g, CH - 1) * CB;  // (chunks past CH meet zero weights)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) xf[set][mt].load(xc + ((mt + ky) * TWH + kx) * PIXB);
+#pragma unroll
+        for (int ct = RW; ct < NCT; ++ct) wf[set][ct - RW].load(wlane + (j / 3) * SS + (j % 3) * KSB + ct * 16 * CB);
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        if (j + 1 < NK) load_frags(j + 1, (j + 1) & 1);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][ct] = mma(ct < RW ? wreg[j][ct < RW ? ct : 0] : wf[j & 1][ct >= RW ? ct - RW : 0], xf[j & 1][mt], acc[mt][ct]);
+      }
+    }
+    barrier();  // Y_it: the store waves have drained patch it-1
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(patch + ((2 * wave + mt) * 16 + px) * PSTR + (ct * 16 + g * 4) * 4) = acc[mt][ct];
+    barrier();  // X_{it+1}: patch it is written (and halo it+1 has landed)
+  }
+}
+
 // ================================================================================================ weight-streaming variant
 // conv_ws_kernel: bf16 3x3, ONE workgroup per 128-pixel tile (8 rows x 16 columns) and per block of NCT*16 output channels
 // (144 or 112: all of them for the convs of the recurrent chains), seven waves with fixed roles:
@@ -1575,6 +1854,36 @@ int launch_linear_wres(const ConvK& k, int ncb, hipStream_t st) {
   return 0;
 }
 
+template <int NCT, int NB, bool FULL>
+int launch_wstat2(const ConvK& k, int ncb, hipStream_t st) {
+  constexpr int SS = stage_stride(3, NCT, 16);
+  constexpr int HB = ((10 * 18 * 9 + 63) / 64) * 1024;
+  constexpr int lds = 3 * NB * SS + 2 * HB + NCT * 16 * 4 + 128 * (NCT * 64 + 16);
+  static_assert(lds <= 160 * 1024, "conv_wstat_kernel: LDS");
+  VMG_CHECK(k.nstages == 3 * NB, "conv (weights-stationary): %d stages in the pack, %d expected", k.nstages, 3 * NB);
+  auto fn = conv_wstat_kernel<NCT, NB, FULL>;
+  static bool attr_set[VMG_MAX_DEVICES] = {};
+  const int dev = vmg_current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[dev] = true;
+  }
+  const long long ntiles = (long long)k.N * k.tiles_y * k.tiles_x;
+  VMG_CHECK(ntiles > 0 && ntiles < (1ll << 30), "conv: bad tile count %lld", ntiles);
+  int nwg = vmg_cu_count(dev) & ~7;  // one workgroup per CU, a multiple of the 8 XCDs
+  if (nwg < 8) nwg = 8;
+  while (nwg > 8 && (long long)(nwg >> 3) > cdiv64(ntiles, 8)) nwg -= 8;  // fewer tiles than workgroups
+  hipLaunchKernelGGL(fn, dim3((unsigned)nwg, ncb), dim3(512), lds, st, k, (int)ntiles);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NCT, int NB>
+int launch_wstat(const ConvK& k, int ncb, hipStream_t st) {
+  const bool full = k.res || k.aux || k.out_pre || k.act == VMG_ACT_GELU;
+  return full ? launch_wstat2<NCT, NB, true>(k, ncb, st) : launch_wstat2<NCT, NB, false>(k, ncb, st);
+}
+
 template <int NCT>
 int launch_ws(const ConvK& k, int ncb, hipStream_t st) {
   using G = WsGeo<NCT>;
@@ -1826,6 +2135,21 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     k.halo_bytes = (halo3 + 1023) & ~1023;  // whole 1-KiB LDS-DMA pieces
     k.tiles_y = cdiv(d->H, 8);
     return ntb == 9 ? launch_ws<9>(k, ncb, st) : launch_ws<7>(k, ncb, st);
+  }
+  if (d->deep == 6 && d->dtype == VMG_BF16 && d->ks == 3 && mt == 1 && k.vec8 && n == 1 && (ntb == 1 || ntb == 3 || ntb == 4) && k.src_ch[0] <= 64 && k.src_ch[0] % 8 == 0 &&
+      k.src_ps[0] % 8 == 0 && d->W <= 255 * 16 && (long long)d->W * k.src_ps[0] * 2 * 10 < (1ll << 31)) {
+    // weights-stationary kernel (a hint: anything it does not cover takes the general kernel below); its tiles are 8 rows high
+    ConvK kk = k;
+    kk.tiles_y = cdiv(d->H, 8);
+    const int nb = (k.src_ch[0] / 8 + 3) / 4;  // 32-channel blocks: 1 or 2
+    switch (ntb * 2 + (nb - 1)) {
+      case 2: return launch_wstat<1, 1>(kk, ncb, st);
+      case 3: return launch_wstat<1, 2>(kk, ncb, st);
+      case 6: return launch_wstat<3, 1>(kk, ncb, st);
+      case 7: return launch_wstat<3, 2>(kk, ncb, st);
+      case 8: return launch_wstat<4, 1>(kk, ncb, st);
+      case 9: return launch_wstat<4, 2>(kk, ncb, st);
+    }
   }
   if (d->deep == 4 && d->dtype == VMG_BF16 && d->ks == 1 && k.vec8 && (ntb == 3 || ntb == 5)) {
     // (a hint: anything it does not cover -- padded LDS stride, several sources, unaligned rows -- takes the general kernel below)

@@ -57,6 +57,11 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
             return 5, 1, 4  # Mlp_cnn.fc2's data gradient: 39 us vs 66 us (tools/bench_linear.py)
         if cout == 144 and src_ch[0] == 288:
             return 3, 1, 4  # Mlp_cnn.fc2 (the 288-channel source as two blocks of the pack): 48 us vs 55 us
+    if dtype == torch.bfloat16 and ks == 3 and not pixel_shuffle and M >= (1 << 18) and src_ch is not None and len(src_ch) == 1 and \
+            src_ch[0] <= 64 and src_ch[0] % 8 == 0 and cout in (16, 48, 64):  # (tile counts the general kernel has too)
+        # the HR head (HRconv 64 -> 64, conv_last's data gradient 8 -> 64; 1.8 M pixels): weights-stationary kernel -- one workgroup per CU keeps
+        # the layer's <= 74 KiB of weights in LDS and walks over 128-pixel tiles (the general kernel re-streams them per 64-pixel workgroup)
+        return cout // 16, 1, 6
     if dtype == torch.bfloat16 and ks == 3 and not pixel_shuffle and M >= (1 << 20) and src_ch is not None and len(src_ch) == 1 and \
             (cout <= 16 or src_ch[0] <= 16):
         return None, 2, 0  # conv_last (64 -> 3) and its data gradient (8 -> 64) on 1.8 M pixels: 18 MFMAs per wave and tile -- 128-pixel tiles halve the workgroup count
