@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/r03_prof -o t -- pyth
 T=$(ls $O/r03_prof/*kernel_trace.csv | head -1)
 cp $(ls $O/r03_prof/*kernel_stats.csv | head -1) $O/r03_j_bench_kernel_stats.csv
 python tools/step_kernels.py $T 60 > $O/r03_j_step_kernels.txt
-python tools/prof_summary.py $T 50 $O/r03_j_bench_laststep_summary.txt
+python tools/prof_summary.py $T 66 $O/r03_j_bench_laststep_summary.txt  # (the step period under the tracer is ~66 ms)
 python tools/kernel_shapes.py $T conv_ > $O/r03_j_conv_launches.txt
 rm -rf $O/r03_prof
 python bench.py > $O/r03_j_bench_train.json 2> $O/r03_j_bench_train.err
