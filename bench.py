@@ -257,7 +257,10 @@ def main():
     if not args.no_prof:
         null_us = float(lib.vmg_prof_null_interval_us(50, hip.stream_ptr()))  # event-pair interval of an empty kernel
         hip.check(lib.vmg_prof_select_pixels(hip.ctx(), k1_pixels), "vmg_prof_select_pixels")
-        hip.check(lib.vmg_prof_begin(hip.ctx(), 3 if args.fp8 else 1, 16, 4096), "vmg_prof_begin")  # class 1: the bf16 conv3x3 C -> C; 3: the fp8 one
+        # every 64th launch of the class is bracketed by an event pair (class 1: the bf16 conv3x3 C -> C; 3: the fp8 one).  An event pair is
+        # not free on this runtime -- ~8 us of stream time per sampled launch: at every 16th launch (54 samples per train step) the sampling
+        # itself cost 0.43 ms per step (A/B against --no-prof); 13 samples per step still give >= 50 per default run
+        hip.check(lib.vmg_prof_begin(hip.ctx(), 3 if args.fp8 else 1, 64, 4096), "vmg_prof_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(lrs, hrs)
