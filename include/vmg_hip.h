@@ -121,7 +121,9 @@ typedef struct vmg_conv_desc {
               * 112 output channels per workgroup, loader waves stream the vmg_convws_pack image through an LDS ring; cout_tiles 9 or 7,
               * 16-byte aligned rows, no pixel_shuffle), 4 = 1x1 with every wave its own pipeline: weights
               * resident in registers, 16-row tiles through wave-private LDS (bf16, one dense source of <= 160 channels,
-              * cout_tiles 3 or 5, 16-byte aligned output rows) */
+              * cout_tiles 3 or 5, 16-byte aligned output rows), 6 = weights-stationary 3x3 (bf16, one source of <= 64 channels,
+              * cout_tiles 1, 3 or 4: a persistent workgroup per CU keeps the packed weights in LDS and walks over 128-pixel tiles;
+              * the HR head, models/vmg.py:629-632).  4 and 6 are hints: a call they do not cover runs on the general kernel */
 } vmg_conv_desc;
 
 int vmg_conv_fwd(const vmg_conv_desc* d, void* stream);
