@@ -65,8 +65,10 @@ def build_model(device, wl=None):
     return m.eval() if infer else m.train()
 
 
-def cpu_baseline(workload="train"):
+def cpu_baseline(workload="train", same=None):
     """The oracle (CPU restatement, fp32, the box's host cores) on a BOUNDED sample of the workload's own job, next to the GPU number.
+    same = (state dict, LR clip, HR target) of the GPU leg (CPU tensors): the train workload's step then runs on EXACTLY the GPU leg's initial
+    weights and clip, and its output / loss are returned for the `parity` object ("PSNR(GPU output, CPU output)").
     train: one whole step of the bench's batch (4 clips x 7 frames x 64x64: forward + loss + backward + AdamW over every parameter, ~20 s);
     train_full / train_swin: one step on ONE clip of 7 frames; train_vimeo: one step on a 1 x 3 x 64 x 112 clip (1/16 of the frame area, 3 of 7
     frames), scaled by pixels; infer: ONE network call on a 5-frame 128 x 128 tile of the 18 x 50-frame calls a sequence needs, scaled."""
@@ -96,6 +98,10 @@ def cpu_baseline(workload="train"):
         pm.spynet = vmg_amd.SPyNet(None)
         shapes = {k: list(v.shape) for k, v in pm.state_dict().items()}
     sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
+    if same is not None and workload == "train":
+        if sorted(same[0]) != sorted(sd):
+            raise SystemExit("bench.py: the product's state dict and the oracle's key list differ")
+        sd = {k: same[0][k].detach().clone() for k in sd}
     for k, v in sd.items():
         if v.dtype.is_floating_point and not R.is_buffer(k):
             v.requires_grad_(True)
@@ -109,26 +115,39 @@ def cpu_baseline(workload="train"):
             c = dataclasses.replace(c, temporal_empty=False)
         return c
 
-    def one_step(b, t, h, w, seed, train=True):
-        x = R.synthetic_clip(b, t, h, w, seed)
+    keep = {}
+
+    def one_step(b, t, h, w, seed, train=True, xy=None):
+        x = R.synthetic_clip(b, t, h, w, seed) if xy is None else xy[0]
         t0 = time.time()
         if train:
-            y = R.synthetic_target(x)
+            y = R.synthetic_target(x) if xy is None else xy[1]
             t0 = time.time()
             out = O.vmg_forward(sd, cfg_for(t), x, mutate=False, call_index=1)
-            O.charbonnier_edge_loss(out, y).backward()
+            loss = O.charbonnier_edge_loss(out, y)
+            loss.backward()
             opt.step()
             opt.zero_grad(set_to_none=True)
+            keep["out"], keep["loss"] = out.detach(), float(loss)
         else:
             with torch.no_grad():
                 O.vmg_forward(sd, cfg_for(t), x, mutate=False, call_index=1)
         return time.time() - t0
 
-    warm = one_step(1, 3 if workload != "train_swin" else 4, 64, 64, 7, train=workload != "infer")
+    if same is not None and workload == "train":
+        # (no separate warm-up pass: it would take an AdamW step on the weights the parity statement is about; the thread pool and the
+        #  allocator are warmed by a forward-only call on a tiny clip instead)
+        t0 = time.time()
+        with torch.no_grad():
+            O.vmg_forward(sd, cfg_for(3), R.synthetic_clip(1, 3, 64, 64, 7), mutate=False, call_index=1)
+        warm = time.time() - t0
+    else:
+        warm = one_step(1, 3 if workload != "train_swin" else 4, 64, 64, 7, train=workload != "infer")
     print("[bench] cpu_baseline warm-up pass %.1f s" % warm, file=sys.stderr, flush=True)
     if workload == "train":
-        dt = one_step(B_PER_GPU, T, 64, 64, 8)
-        value, sample = B_PER_GPU * T / dt, "one train step of the bench's own job: %d clips x %d frames x 64x64, fp32, forward+loss+backward+AdamW (%.1f s)" % (B_PER_GPU, T, dt)
+        dt = one_step(B_PER_GPU, T, 64, 64, 8, xy=None if same is None else (same[1], same[2]))
+        value, sample = B_PER_GPU * T / dt, "one train step of the bench's own job%s: %d clips x %d frames x 64x64, fp32, forward+loss+backward+AdamW (%.1f s)" % (
+            " on the GPU leg's own initial weights and clip" if same is not None else "", B_PER_GPU, T, dt)
     elif workload in ("train_full", "train_swin"):
         dt = one_step(1, 7, 64, 64, 8)
         value, sample = 7 / dt, "one train step on ONE clip of 7 frames x 64x64 (the bench's batch is %s), fp32, forward+loss+backward+AdamW (%.1f s)" % ("the same" if full else "4 such clips", dt)
@@ -141,8 +160,17 @@ def cpu_baseline(workload="train"):
         value = 100.0 / (18 * 10 * dt)
         sample = "ONE forward call on a 5-frame 128 x 128 tile (%.1f s); a 100-frame 180 x 320 sequence needs 18 calls of 50 frames: value = 100 / (180 x that time)" % dt
     print("[bench] cpu_baseline sample %.1f s" % dt, file=sys.stderr, flush=True)
-    return {"value": round(value, 4), "unit": "LR-frames/s", "cores": os.cpu_count() or threads, "threads": threads, "affinity_cores": naff, "kind": "port",
-            "sample": sample + "; warm-up pass before it: %.1f s" % warm}
+    res = {"value": round(value, 4), "unit": "LR-frames/s", "cores": os.cpu_count() or threads, "threads": threads, "affinity_cores": naff, "kind": "port",
+           "sample": sample + "; warm-up pass before it: %.1f s" % warm}
+    return (res, keep) if same is not None else res
+
+
+def psnr_u8(a, b):
+    """PSNR after the reference's clamp / x255 / round (tools/Tester.py:249-250, utils/metrics.py:11-26)."""
+    import math
+    qa, qb = (a.clamp(0, 1) * 255).round().double(), (b.clamp(0, 1) * 255).round().double()
+    mse = float(((qa - qb) ** 2).mean())
+    return float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
 
 
 def main():
@@ -205,6 +233,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     B, Tn, S = wl["batch"], wl["frames"], wl["size"]
+    parity_gpu = None
     model = build_model(device, wl)
     model.recompute_chains = bool(args.recompute)
     model.fp8_chains = bool(args.fp8)
@@ -219,10 +248,25 @@ def main():
         hrs = None
         k1_pixels = 2 * 1 * S * S
     else:
-        step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
         Hh, Ww = S if isinstance(S, tuple) else (S, S)
         lrs = synthetic_clip(B, Tn, Hh, Ww, seed=1234 + rank, device=device)
         hrs = synthetic_target(lrs, seed=4321 + rank)
+        if args.workload == "train" and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # parity of the benchmarked batch itself (outside the timed region): the network's output for the bench's own clip and INITIAL weights,
+            # call #1, DropPath off (eval mode: the oracle draws no masks) -- at this batch the recurrent chains take the
+            # weight-streaming route (M = 32 768 pixels), the one the roofline object prices.  The oracle computes the same call on the host
+            # cores as part of the cpu_baseline step below.
+            from vmg_amd.train import charbonnier_edge_loss_hip
+            sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            model.eval()
+            with torch.no_grad():
+                out0 = model(lrs)
+                loss0 = float(charbonnier_edge_loss_hip(out0.float(), hrs.float(), 1e-12, 0.005))
+            model.train()
+            model.load_state_dict(sd0)  # (the call decayed the MorphFC mixer weights once: put the initial weights back)
+            parity_gpu = (out0.float().cpu(), loss0, {k: v.cpu() for k, v in sd0.items()}, lrs.cpu(), hrs.cpu())
+            del out0, sd0
+        step = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005, distributed=distributed)
         k1_pixels = 2 * B * Hh * Ww  # one frame of every clip for BOTH direction sweeps (run in lockstep)
     k1_flops = 2.0 * wl["ch"] * wl["ch"] * 9 * k1_pixels  # algorithmic FLOPs of one launch of the dominant kernel
 
@@ -324,14 +368,27 @@ def main():
     elif args.graph:
         line["config"]["launch"] = "hipgraph (vmg_amd.infer.GraphedModel: one captured network call, replayed per tile)"
         line["roofline"] = None
-        line["config"]["recompute_chains"] = bool(args.recompute)
-        line["config"]["fp8_chains"] = bool(args.fp8)
-        line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
+    line["config"]["recompute_chains"] = bool(args.recompute)
+    line["config"]["fp8_chains"] = bool(args.fp8)
+    line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     if args.workload == "train":
         line["config"]["model_tflops"] = round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2)
     if rank == 0:
+        line["parity"] = None
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+            if parity_gpu is not None:
+                out_gpu, loss_gpu, sd0, x0, y0 = parity_gpu
+                line["cpu_baseline"], kept = cpu_baseline(args.workload, same=(sd0, x0, y0))
+                out_cpu = kept["out"]
+                line["parity"] = {
+                    "what": "network output and Charbonnier+edge loss for the bench's own clip and initial weights, forward call #1, DropPath off: "
+                            "HIP bf16 (this GPU, the weight-streaming chain route at M = 32768 px) vs the CPU oracle in fp32 (the cpu_baseline step's own forward)",
+                    "psnr_db": round(psnr_u8(out_gpu, out_cpu), 2), "max_abs": round(float((out_gpu - out_cpu).abs().max()), 5),
+                    "loss_gpu": loss_gpu, "loss_cpu": kept["loss"],
+                    "psnr_gpu_vs_target_db": round(psnr_u8(out_gpu, y0), 3), "psnr_cpu_vs_target_db": round(psnr_u8(out_cpu, y0), 3),
+                    "stated_tolerance": "bf16: PSNR(hip, oracle) >= 40 dB, loss within 2 % (DESIGN.md section 2)"}
+            else:
+                line["cpu_baseline"] = cpu_baseline(args.workload)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -10,6 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SPYNET_BF16_BOUND = 0.2  # relative L2 of SPyNet's parameter gradients in bf16 runs (see test_bf16_whole_model_gradients; shared with tests/test_bench_batch_gpu.py)
 
 
 def _oracle_grads(sd, cfg, x, tgt, want_out=False):
@@ -140,7 +141,7 @@ def test_bf16_whole_model_gradients(which):
     print(f"bf16 {which} gradients: cosine {cos:.5f}, worst relative L2 {worst[0]:.4f} at {worst[1]}; SPyNet: {worst_spy[0]:.4f} at {worst_spy[1]}")
     assert cos >= 0.999, cos
     assert worst[0] <= 0.04, worst
-    assert worst_spy[0] <= 0.2, worst_spy
+    assert worst_spy[0] <= SPYNET_BF16_BOUND, worst_spy
 
 
 def test_recompute_chains_gives_the_same_gradients():

@@ -138,3 +138,40 @@ def test_graphed_model_gives_the_same_bits_and_keeps_the_call_count(dtype):
     assert torch.equal(res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k  # the same number of decays has been applied
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graphed_model_two_shapes_a_b_a(dtype):
+    """GraphedModel keeps one hipGraph per input shape, and every graph has baked in the addresses of the one-launch repack
+    plan's entry table and of the weight packs it rewrites.  A call at a second shape creates new packs (other tilings) and rebuilds the plan:
+    the first graph must still replay correctly afterwards (the superseded table is retired, not freed; stale packs are rewritten in place).
+    Calls A, B, A, B through the wrapper == the same four eager calls on a second model, bit for bit, including the per-call weight decay."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from tests.util import build_product
+    from vmg_amd import infer
+    from vmg_amd import functional as FH
+    case = C.CASES["infer_vmg_clips"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "infer_vmg_clips.npz"))
+    sd = C.case_state_dict(case, shapes)
+    xa = R.synthetic_clip(1, 3, 64, 64, 95).cuda()
+    xb = R.synthetic_clip(1, 3, 96, 80, 96).cuda()
+    res = []
+    for graphed in (False, True):
+        FH.clear_pack_cache()
+        m = build_product(case["cfg"], dtype)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        net = infer.GraphedModel(m) if graphed else m
+        outs = []
+        with torch.no_grad():
+            for x in (xa, xb, xa, xb):
+                outs.append(net(x).float().cpu().clone())
+                # allocator churn between the calls: a freed plan table / pack buffer would be handed out again here and overwritten
+                junk = [torch.full((1 << 12,), 7.0, device="cuda") for _ in range(64)]
+                del junk
+        res.append(outs)
+        if graphed:
+            assert len(net.graphs) == 2
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), f"call {i}: graphed and eager results differ"

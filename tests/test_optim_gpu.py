@@ -290,3 +290,107 @@ def test_train_step_schedule_clip_and_accumulation():
         ref = 0.5 * (single[0][n] + single[1][n])
         # (5e-3 of the gradient's scale as in tests/test_grad_gpu.py: LayerNorm's weight gradient is a cancelling sum over 12 288 rows)
         assert float((got[n] - ref).abs().max()) <= 5e-3 * max(float(ref.abs().max()), 1e-3 * gmax), n
+
+
+def test_captured_step_advances_the_schedule_and_state_dict_resumes():
+    """the learning-rate schedule must progress under replay() -- the capture pass and every replay used to leave
+    `schedule.step` / `iter` untouched, so warm-up, cosine decay and SPyNet's flow_fix unfreeze never happened in a captured run.  After k eager
+    warm-up steps (they are real optimizer steps and count) and N replays the groups' rates are row k + N - 1 of the reference's
+    update_learning_rate recursion (oracle_lr_update, pinned by tests/golden/lr_update.npz), SPyNet has moved once cur_iter passed flow_fix,
+    and TrainStep.state_dict() -> load_state_dict() resumes iter / schedule / optimizer (tools/Trainer.py:355-365)."""
+    from oracle import cases as C
+    from tests.util import build_product
+    from vmg_amd.train import TrainStep
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    import os
+    cfg = C.cfg_tiny_few(3, is_train=False)
+    shapes, _ = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(C.CASES["vmg_tiny_few"], shapes)
+    x = synthetic_clip(1, 3, 64, 64, seed=75, device="cuda")
+    y = synthetic_target(x)
+    sched = dict(T_period=[40], eta_min=1e-7, flow_fix=6, pre_lr_ratio=0.125, warmup_iter=3)
+    m = build_product(cfg, torch.float32)
+    m.load_state_dict(sd)
+    m.train()
+    ts = TrainStep(m, lr=2e-4, schedule=dict(sched))
+    spy0 = torch.cat([p.detach().reshape(-1).clone() for p in m.spynet.parameters()])
+    ts.capture(x, y, warmup=2)
+    k = ts.iter
+    assert 2 <= k <= 8, k                     # the eager warm-up steps; the capture pass itself is not a step
+    assert ts.schedule.epoch == k
+    want = C.oracle_lr_update(dict(T_period=[40], restarts=None, weights=None, eta_min=1e-7, base=[0.0, 2e-4], flow_fix=6, pre_lr_ratio=0.125,
+                                   warmup_iter=3, reduced_iter=None, steps=k + 6))
+    assert [g["lr"] for g in ts.opt.param_groups] == want[k - 1]
+    frozen_until = None
+    for n in range(6):
+        ts(x, y)
+        assert ts.iter == k + n + 1
+        assert [g["lr"] for g in ts.opt.param_groups] == want[k + n], (n, k)
+        torch.cuda.synchronize()
+        spy = torch.cat([p.detach().reshape(-1) for p in m.spynet.parameters()])
+        if torch.equal(spy, spy0):
+            frozen_until = ts.iter
+    # step number i (0-based) runs with the rates update_learning_rate(i - 1) left: SPyNet's is 0 while i - 1 <= flow_fix, i.e. steps 0 .. 7
+    assert frozen_until == min(k + 6, 8), (frozen_until, k)
+    assert (k + 6 <= 8) or not torch.equal(spy, spy0)
+
+    state = ts.state_dict()
+    m2 = build_product(cfg, torch.float32)
+    m2.load_state_dict(sd)
+    m2.train()
+    t2 = TrainStep(m2, lr=2e-4, schedule=dict(sched))
+    t2.load_state_dict(state)
+    assert t2.iter == ts.iter and t2.schedule.epoch == ts.schedule.epoch and t2.opt.t == ts.opt.t
+    assert [g["lr"] for g in t2.opt.param_groups] == [g["lr"] for g in ts.opt.param_groups]
+    with pytest.raises(ValueError):
+        TrainStep(m2, lr=2e-4).load_state_dict(state)
+
+
+def test_accumulation_clips_every_micro_step_like_the_reference():
+    """tools/Trainer.py:179-180: with gradient accumulation the reference clips after EVERY micro-step's backward, so the partial sum is
+    rescaled before the next micro-step adds to it.  Two micro-steps with a tight max_norm: the buffer after micro-step 1 has norm <= max_norm,
+    and the final gradient equals clip(clip(g1) + g2) built from two separately measured gradients."""
+    from oracle import cases as C
+    from tests.util import build_product
+    from vmg_amd.train import TrainStep
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    import os
+    cfg = C.cfg_tiny_few(3, is_train=False)
+    shapes, _ = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(C.CASES["vmg_tiny_few"], shapes)
+    xs = [synthetic_clip(1, 3, 64, 64, seed=80 + i, device="cuda") for i in range(2)]
+    ys = [synthetic_target(x) for x in xs]
+
+    def fresh(clip):
+        mm = build_product(cfg, torch.float32)
+        mm.load_state_dict(sd)
+        mm.train()
+        return mm, TrainStep(mm, lr=0.0, grad_clip=clip)
+    max_norm = 1e-3
+    m1, t1 = fresh(max_norm)
+    t1(xs[0], ys[0], grad_acc=2, update=False)
+    n1 = float(t1.opt.g.double().square().sum().sqrt())
+    assert n1 <= max_norm * (1 + 1e-5) and float(t1.grad_norm[0]) > max_norm  # micro-step 1 was clipped
+    got = {}
+    t1.grad_hook = lambda t: got.update({n: p.grad.clone() for n, p in m1.named_parameters()})
+    t1(xs[1], ys[1], grad_acc=2, update=True)
+    raw = []
+    for i in range(2):
+        m2, t2 = fresh(None)
+        for j in range(i):
+            with torch.no_grad():
+                m2(xs[j])  # (T1: micro-step i runs on mixer weights decayed i + 1 times)
+        g2 = {}
+        t2.grad_hook = lambda t, g2=g2, m2=m2: g2.update({n: p.grad.clone() for n, p in m2.named_parameters()})
+        t2(xs[i], ys[i], grad_acc=2, update=True)
+        raw.append(g2)
+
+    def clip(gs):
+        tot = float(torch.sqrt(sum(v.double().square().sum() for v in gs.values())))
+        c = min(1.0, max_norm / (tot + 1e-6))
+        return {n: v * c for n, v in gs.items()}
+    step1 = clip(raw[0])
+    want = clip({n: step1[n] + raw[1][n] for n in step1})
+    gmax = max(float(v.abs().max()) for v in want.values())
+    for n in got:
+        assert float((got[n] - want[n]).abs().max()) <= 5e-3 * max(float(want[n].abs().max()), 1e-3 * gmax), n

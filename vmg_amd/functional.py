@@ -92,6 +92,10 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
     if hit is not None and hit[0][1] == ver[1] and key not in _PACK_VOLATILE:
         _PACK_VOLATILE.add(key)  # modified in place between optimizer steps (the MorphFC decay, T1): repack_all leaves it alone
         _PACK_STAMP[0] += 1
+    # a stale pack of this very parameter is REWRITTEN IN PLACE (stream order protects its earlier readers): its buffer's address may be baked
+    # into a captured hipGraph (the pack node and the convolutions that read it), so it must neither move nor return to the allocator while
+    # the parameter lives -- an eager call between replays used to re-create it and free the buffer the graph still wrote through
+    buf0 = hit[1].buf if (hit is not None and hit[2] is weight) else None
     w = weight.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -118,18 +122,18 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
             src_ch = [_pad_to(c) for c in src_ch]
         o0, no = (orange[0], orange[1]) if orange else (0, None)
         if deep == 3:
-            pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no)
+            pw = K.pack_conv_weight_ws(w.contiguous(), src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no, out=buf0)
         else:
-            pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no)
+            pw = K.pack_conv_weight(w.contiguous(), dtype, src_ch=list(src_ch), cout_tiles=tiles, o0=o0, on=no, out=buf0)
     elif kind == "dgrad":
         on = I - i0 if on is None else on
         if orange:
             if orange[1] % 8:
                 raise HipError("grouped data-gradient pack: the group's output channel count must be a multiple of 8")
             if deep == 3:
-                pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]])
+                pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]], out=buf0)
             else:
-                pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]])
+                pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, src_off=[orange[0]], src_ch=[orange[1]], out=buf0)
             if key not in _PACK_VOLATILE and pw.call is not None and pw.call[0] == weight.data_ptr():
                 _PACK_STAMP[0] += 1
             _PACK_CACHE[key] = [ver, pw, weight]
@@ -139,9 +143,9 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
             wp[:O].add_(w)  # (an add kernel into the zeros: a contiguous copy_ would be a memcpy node, see the forward pack)
             w = wp
         if deep == 3:
-            pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
+            pw = K.pack_conv_weight_ws(w.contiguous(), o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, out=buf0)
         else:
-            pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles)
+            pw = K.pack_conv_weight(w.contiguous(), dtype, o0=i0, on=on, transpose_flip=True, cout_tiles=tiles, out=buf0)
     else:
         raise HipError(kind)
     if key not in _PACK_VOLATILE and pw.call is not None and pw.call[0] == weight.data_ptr():
@@ -691,7 +695,7 @@ def packed_q8(weight: torch.Tensor) -> K.PackedQ8:
     hit = _Q8_CACHE.get(id(weight))
     if hit is not None and hit[0] == ver and hit[2] is weight:
         return hit[1]
-    pw = K.pack_conv_weight_q8(weight.detach().contiguous())
+    pw = K.pack_conv_weight_q8(weight.detach().contiguous(), out=hit[1].buf if (hit is not None and hit[2] is weight) else None)
     _Q8_CACHE[id(weight)] = (ver, pw, weight)
     return pw
 

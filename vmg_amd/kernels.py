@@ -108,8 +108,9 @@ def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -
 
 
 def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None, src_off: Optional[Sequence[int]] = None, o0: int = 0,
-                        on: Optional[int] = None, transpose_flip: bool = False, cout_tiles: int = 9) -> PackedConv:
-    """bf16 pack of a 3x3 weight (O, I, 3, 3) for the weight-streaming kernel (same slicing conventions as pack_conv_weight)."""
+                        on: Optional[int] = None, transpose_flip: bool = False, cout_tiles: int = 9, out: Optional[torch.Tensor] = None) -> PackedConv:
+    """bf16 pack of a 3x3 weight (O, I, 3, 3) for the weight-streaming kernel (same slicing conventions as pack_conv_weight).
+    out: an existing pack buffer of this very pack to rewrite in place."""
     hip.require_cuda(w)
     if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
         raise HipError("pack_conv_weight_ws expects a contiguous fp32 (O, I, 3, 3) weight")
@@ -128,7 +129,10 @@ def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None,
     nbytes = l.vmg_convws_pack_bytes(on, len(src_ch), _intarr(src_ch), cout_tiles)
     if nbytes <= 0:
         raise HipError(f"vmg_convws_pack_bytes rejected channels {list(src_ch)} / cout_tiles {cout_tiles}")
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    elif out.numel() * out.element_size() < nbytes:
+        raise HipError("pack buffer too small")
     hip.check(l.vmg_convws_pack(w.data_ptr(), O, I, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch), 1 if transpose_flip else 0,
                                 cout_tiles, out.data_ptr(), hip.stream_ptr()), "vmg_convws_pack")
     return PackedConv(out, torch.bfloat16, 3, on, src_ch, cout_tiles, layout="ws",
@@ -228,6 +232,9 @@ def _parr(ts):
     return (ctypes.c_void_p * max(1, len(ts)))(*[(t.data_ptr() if t is not None else None) for t in ts])
 
 
+CHAIN_STATS = {"fwd": {}, "bwd": {}}  # chain calls by the `deep` route their block convolutions took (3: weight-streaming, 2: K-split, ...): read by tests
+
+
 def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: torch.Tensor, slope0: float, deep0: int, pw1: Sequence[PackedConv],
                            b1: Sequence[torch.Tensor], pw2: Sequence[PackedConv], b2: Sequence[torch.Tensor], r_scaling: float, deep: int,
                            own_output: bool = False):
@@ -262,6 +269,7 @@ def resblock_chain_forward(srcs: Sequence[torch.Tensor], pw0: PackedConv, b0: to
     d.cout_tiles = pw1[0].cout_tiles if nblk else pw0.cout_tiles
     d.deep = (3 if pw1[0].layout == "ws" else deep) if nblk else 0
     hip.check(hip.lib().vmg_resblock_chain_fwd(ctypes.byref(d), hip.stream_ptr()), "vmg_resblock_chain_fwd")
+    CHAIN_STATS["fwd"][d.deep] = CHAIN_STATS["fwd"].get(d.deep, 0) + 1
     return ys, ts
 
 
@@ -285,6 +293,7 @@ def resblock_chain_backward(g: torch.Tensor, ts: Sequence[torch.Tensor], pd1: Se
     d.cout_tiles = pd1[0].cout_tiles
     d.deep = 3 if pd1[0].layout == "ws" else deep
     hip.check(hip.lib().vmg_resblock_chain_bwd(ctypes.byref(d), hip.stream_ptr()), "vmg_resblock_chain_bwd")
+    CHAIN_STATS["bwd"][d.deep] = CHAIN_STATS["bwd"].get(d.deep, 0) + 1
     return gys, gts
 
 
@@ -932,6 +941,10 @@ class PackPlan:
 
     def __init__(self):
         self.sig, self.dev, self.n, self.blocks = None, None, 0, 0
+        # superseded entry tables are never freed: a captured hipGraph (train.TrainStep.capture, infer.GraphedModel) has the table's ADDRESS
+        # baked into its vmg_pack_run node, and a later plan rebuild (an eager call at another shape creates new packs) must not hand that
+        # memory back to the allocator while the graph can still be replayed.  A table is ~100 B per pack; plans are rebuilt a handful of times.
+        self.retired = []
 
     def run(self, packs: Sequence[PackedConv], reuse: bool = False):
         """reuse: the caller guarantees that `packs` is the list of the previous call unless it has reset self.sig to None."""
@@ -955,6 +968,8 @@ class PackPlan:
                 if nb <= 0:
                     hip.check(nb if nb < 0 else -1, "vmg_pack_entry")
                 blk += nb
+            if self.dev is not None:
+                self.retired.append(self.dev)
             self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(packs[0].buf.device)
             self.sig, self.n, self.blocks = sig, len(packs), blk
         hip.check(l.vmg_pack_run(self.dev.data_ptr(), self.n, self.blocks, hip.stream_ptr()), "vmg_pack_run")
@@ -993,7 +1008,7 @@ class PackedQ8:
         self.buf, self.cout, self.cin, self.call = buf, cout, cin, call
 
 
-def pack_conv_weight_q8(w: torch.Tensor, transpose_flip: bool = False) -> PackedQ8:
+def pack_conv_weight_q8(w: torch.Tensor, transpose_flip: bool = False, out: Optional[torch.Tensor] = None) -> PackedQ8:
     """fp32 (O, I, 3, 3) -> the fp8 convolution's weight image (vmg_convq8_pack): e4m3 with one power-of-two scale per output channel."""
     hip.require_cuda(w)
     if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
@@ -1003,7 +1018,7 @@ def pack_conv_weight_q8(w: torch.Tensor, transpose_flip: bool = False) -> Packed
     nbytes = hip.lib().vmg_convq8_pack_bytes(cout, cin)
     if nbytes <= 0:
         raise HipError(f"vmg_convq8_pack_bytes: {hip.lib().vmg_last_error().decode()}")
-    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=w.device)
+    buf = out if (out is not None and out.numel() >= int(nbytes)) else torch.empty(int(nbytes), dtype=torch.uint8, device=w.device)
     hip.check(hip.lib().vmg_convq8_pack(w.data_ptr(), O, I, 1 if transpose_flip else 0, buf.data_ptr(), hip.stream_ptr()), "vmg_convq8_pack")
     return PackedQ8(buf, cout, cin, (w.data_ptr(), O, I, 1 if transpose_flip else 0))
 

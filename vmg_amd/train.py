@@ -661,13 +661,34 @@ class TrainStep:
             self._static[0].copy_(lrs)
             self._static[1].copy_(hrs)
         if isinstance(self.opt, FlatAdamW):
-            self.opt.advance()
+            self.opt.advance()  # uploads THIS step's scalars: the learning rates the previous step's schedule.step() left in the groups
         if getattr(self, "_replay", None) is not None:
             from . import hip
             hip.check(hip.lib().vmg_replay_run(self._replay, 0, self._replay_ops, hip.stream_ptr()), "vmg_replay_run")
         else:
             self.graph.replay()
+        self._after_update()  # host-side bookkeeping of the step the graph has just run (the capture pass itself skipped it)
         return self._loss
+
+    def _after_update(self):
+        """Trainer.update_learning_rate(step) (tools/Trainer.py:153, 176, 189): the NEXT step's learning rates, then cur_iter + 1.  Host-side
+        only; runs after every optimizer step, eager or replayed (FlatAdamW.advance() uploads the groups' rates at the start of the next step)."""
+        if self.schedule is not None:
+            self.schedule.step(self.iter)
+        self.iter += 1
+
+    def state_dict(self):
+        """What tools/Trainer.py:355-365 saves as the training state ({epoch, iter, scheduler, optimizer}): optimizer moments / step count /
+        group rates, the schedule's recursion state and cur_iter -- a resumed run continues the warm-up / flow_fix / cosine position."""
+        return {"iter": self.iter, "opt": self.opt.state_dict(), "schedule": None if self.schedule is None else self.schedule.state_dict()}
+
+    def load_state_dict(self, sd):
+        if (sd.get("schedule") is None) != (self.schedule is None):
+            raise ValueError("TrainStep.load_state_dict: the checkpoint and this step disagree on having a learning-rate schedule")
+        self.opt.load_state_dict(sd["opt"])
+        if self.schedule is not None:
+            self.schedule.load_state_dict(sd["schedule"])
+        self.iter = int(sd["iter"])
 
     def __call__(self, lrs: torch.Tensor, hrs: torch.Tensor, grad_acc: int = 1, update: bool = True) -> torch.Tensor:
         """One sample (tools/Trainer.py:125-190).  grad_acc / update: gradient accumulation as in the reference's `revise_epoch` branch --
@@ -693,15 +714,18 @@ class TrainStep:
             loss = loss / grad_acc
         loss.backward()
         self._flush()
-        if not update:
-            return loss.detach()
-        if self.reducer is not None:
+        if update and self.reducer is not None:
             self.reducer.finish()
         if self.grad_clip is not None:
+            # the reference clips after EVERY micro-step's backward (tools/Trainer.py:166-167, 179-180), i.e. the partially accumulated sum is
+            # rescaled each time -- reproduced as is.  (Data-parallel: its non-updating micro-steps clip the all-reduced partial sum, ours the
+            # local one, because the exchange happens once per update -- the documented deviation of __call__.)
             if isinstance(self.opt, FlatAdamW):
                 self.grad_norm = self.opt.clip_grad_norm_(self.grad_clip)
             else:
                 self.grad_norm = torch.nn.utils.clip_grad_norm_([p for g in self.opt.param_groups for p in g["params"]], self.grad_clip, norm_type=2)
+        if not update:
+            return loss.detach()
         if self.grad_hook is not None:
             self.grad_hook(self)
         if isinstance(self.opt, FlatAdamW):
@@ -714,9 +738,8 @@ class TrainStep:
         else:
             self.opt.step()
         self.opt.zero_grad(set_to_none=True)
-        if self.schedule is not None:
-            self.schedule.step(self.iter)  # Trainer.update_learning_rate(step): the next step's learning rates
-        self.iter += 1
+        if not (loss.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._after_update()  # (the capture pass runs no kernels: it is not a step; replay() does the bookkeeping per replayed step)
         if self.reducer is not None:
             self.reducer.relayout_by_completion()  # once, after the first step: buckets follow the measured completion order
         return loss.detach()
