@@ -173,6 +173,48 @@ def psnr_u8(a, b):
     return float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
 
 
+def run_extra(workload, device, steps, warmup, graph):
+    """A short timed run of another BASELINE configuration in the same process, AFTER the headline timing (so the driver's default run times
+    them too): train_full = the per-GPU shard of configs[2] replayed from a captured hipGraph, infer = configs[3] (one 100-frame sequence per
+    step).  Same discipline as the headline: W untimed warm-up steps, K timed steps between synchronisations, inputs resident in HBM."""
+    from vmg_amd import infer
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    from vmg_amd.train import TrainStep
+    wl = WORKLOADS[workload]
+    B, Tn, S = wl["batch"], wl["frames"], wl["size"]
+    model = build_model(device, wl)
+    mode = "eager"
+    if workload == "infer":
+        lrs = synthetic_clip(1, Tn, 180, 320, seed=7, device=device)
+        net = infer.GraphedModel(model) if graph else model
+        if graph:
+            mode = "hipgraph (one captured network call, replayed per tile)"
+
+        def step():
+            with torch.no_grad():
+                return infer.to_uint8(infer.test_clips(net, lrs, 50, 25, [128, 128], 20, 4))
+    else:
+        ts = TrainStep(model, lr=2e-4, betas=(0.9, 0.99), aux=True, aux_ratio=0.005)
+        lrs = synthetic_clip(B, Tn, S, S, seed=1234, device=device)
+        hrs = synthetic_target(lrs, seed=4321)
+        if graph:
+            ts.capture(lrs, hrs, warmup=max(1, warmup))
+            mode = "hipgraph"
+
+        def step():
+            return ts(lrs, hrs)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": wl["name"], "value": round(B * Tn * steps / dt, 3), "unit": "LR-frames/s", "ms_per_step": round(dt / steps * 1e3, 2),
+            "steps": steps, "warmup": warmup, "launch": mode}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +226,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="VMG(fp8_chains=True): conv1 / conv2 of the recurrent chains' residual blocks in fp8 (e4m3, block-scaled "
                     "MFMA; SURVEY 8f-4 / BASELINE configs[4]) in the forward pass; the roofline object then prices the fp8 kernel against the 5 PFLOP/s fp8 peak")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configurations that the default "
+                    "(--workload train, one GPU) run appends as `extra_workloads`")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
                     "HIP-event roofline needs eager launches, so eager is the default)")
     ap.add_argument("--recompute", action="store_true", help="VMG(recompute_chains=True): the recurrent residual chains keep only their inputs and "
@@ -373,6 +417,21 @@ def main():
     line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     if args.workload == "train":
         line["config"]["model_tflops"] = round(3 * FWD_GFLOP_PER_FRAME * value / 1e3, 2)
+    if args.workload == "train" and world == 1 and not args.no_extras and not args.graph:
+        # the other single-GPU configurations, timed by the same run (only the default workload was driver-timed).
+        # After the headline's timed region; an extra that fails is reported as such and never takes the headline down with it.
+        extras = []
+        del step, model
+        from vmg_amd import functional as FH
+        for name, st_, wu_, gr_ in (("train_full", 8, 2, True), ("infer", 1, 1, True)):
+            try:
+                FH.clear_pack_cache()
+                torch.cuda.empty_cache()
+                extras.append(run_extra(name, device, st_, wu_, gr_))
+            except Exception as e:
+                extras.append({"workload": WORKLOADS[name]["name"], "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+            print("[bench] extra workload %s done" % name, file=sys.stderr, flush=True)
+        line["extra_workloads"] = extras
     if rank == 0:
         line["parity"] = None
         if not args.no_cpu_baseline and world == 1:

@@ -328,8 +328,11 @@ def test_captured_step_advances_the_schedule_and_state_dict_resumes():
         assert [g["lr"] for g in ts.opt.param_groups] == want[k + n], (n, k)
         torch.cuda.synchronize()
         spy = torch.cat([p.detach().reshape(-1) for p in m.spynet.parameters()])
+        assert torch.isfinite(spy).all(), ts.iter
         if torch.equal(spy, spy0):
             frozen_until = ts.iter
+        else:
+            print(f"iter {ts.iter}: SPyNet moved by {float((spy - spy0).abs().max()):.3e} (lr group 0 was {want[k + n - 1][0]:.3e})")
     # step number i (0-based) runs with the rates update_learning_rate(i - 1) left: SPyNet's is 0 while i - 1 <= flow_fix, i.e. steps 0 .. 7
     assert frozen_until == min(k + 6, 8), (frozen_until, k)
     assert (k + 6 <= 8) or not torch.equal(spy, spy0)

@@ -12,13 +12,19 @@ dt = torch.bfloat16
 w0 = torch.randn(C, 2 * C, 3, 3, device="cuda") * (2 * C * 9) ** -0.5
 ws = [torch.randn(C, C, 3, 3, device="cuda") * (C * 9) ** -0.5 for _ in range(2 * nblk)]
 bs = [torch.zeros(C, device="cuda") for _ in range(2 * nblk + 1)]
-pw0 = K.pack_conv_weight_ws(w0, src_ch=[C, C])
-pw1 = [K.pack_conv_weight_ws(w) for w in ws[:nblk]]
-pw2 = [K.pack_conv_weight_ws(w) for w in ws[nblk:]]
+DEEP = int(sys.argv[1]) if len(sys.argv) > 1 else 3  # 3: weight-streaming kernel (one 159 KB workgroup per CU); 2: K-split kernel (three workgroups per CU)
+if DEEP == 3:
+    pw0 = K.pack_conv_weight_ws(w0, src_ch=[C, C])
+    pw1 = [K.pack_conv_weight_ws(w) for w in ws[:nblk]]
+    pw2 = [K.pack_conv_weight_ws(w) for w in ws[nblk:]]
+else:
+    pw0 = K.pack_conv_weight(w0, dt, src_ch=[C, C], cout_tiles=3)
+    pw1 = [K.pack_conv_weight(w, dt, src_ch=[C], cout_tiles=3) for w in ws[:nblk]]
+    pw2 = [K.pack_conv_weight(w, dt, src_ch=[C], cout_tiles=3) for w in ws[nblk:]]
 
 
 def chain(x, f):
-    return K.resblock_chain_forward([x, f], pw0, bs[0], 0.1, 3, pw1, bs[1:nblk + 1], pw2, bs[nblk + 1:], 0.1, 3)
+    return K.resblock_chain_forward([x, f], pw0, bs[0], 0.1, DEEP, pw1, bs[1:nblk + 1], pw2, bs[nblk + 1:], 0.1, DEEP)
 
 
 def timed(fn, reps=10):
@@ -60,6 +66,7 @@ def halves_serial():
     chain(xb, fb)
 
 
+print("route deep = %d" % DEEP)
 print("one chain, 8 frames           : %.1f us (31 convs, M = 32768)" % timed(one))
 print("two chains of 4 frames, serial: %.1f us" % timed(halves_serial))
 print("two chains of 4 frames, 2 streams: %.1f us" % timed(two))

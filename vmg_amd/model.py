@@ -619,6 +619,7 @@ class VMG(nn.Module):
         self.if_print = if_print
         self.init_H, self.init_W = image_size
         self.compute_dtype = compute_dtype
+        self.spynet_dtype = None  # None: SPyNet computes in compute_dtype; torch.float32: the flow network alone in fp32 (tools/spynet_grad_attrib.py)
         self.recompute_chains = bool(recompute_chains)  # the recurrent residual chains keep their inputs only and are re-run in the backward
         self.fp8_chains = bool(fp8_chains)  # conv1 / conv2 of the chains' residual blocks in fp8 (e4m3, block-scaled; compute_dtype bf16, 144 / 112 channels)
         self.spynet = SPyNet(spynet_pretrained) if spynet_pretrained is not None else None
@@ -698,10 +699,10 @@ class VMG(nn.Module):
             a = xi[:, :-1].reshape(-1, C, h, w)
             b = xi[:, 1:].reshape(-1, C, h, w)
             if self.frames_mirror:
-                ff = self.spynet(b, a, self.compute_dtype).reshape(B, T - 1, 2, h, w)
+                ff = self.spynet(b, a, self.spynet_dtype or self.compute_dtype).reshape(B, T - 1, 2, h, w)
                 fb = ff.flip(1)
             else:  # both directions in ONE SPyNet pass (twice the batch, half the launches; per-sample results unchanged)
-                both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0), self.compute_dtype).contiguous()
+                both = self.spynet(torch.cat([b, a], 0), torch.cat([a, b], 0), self.spynet_dtype or self.compute_dtype).contiguous()
                 ff, fb = FH.split_halves(both)
                 ff, fb = ff.reshape(B, T - 1, 2, h, w), fb.reshape(B, T - 1, 2, h, w)
             fwd.append(ff)
