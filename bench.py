@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="VMG(fp8_chains=True): conv1 / conv2 of the recurrent chains' residual blocks in fp8 (e4m3, block-scaled "
                     "MFMA; SURVEY 8f-4 / BASELINE configs[4]) in the forward pass; the roofline object then prices the fp8 kernel against the 5 PFLOP/s fp8 peak")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--spynet-edge-fp32", type=int, default=-1, help="override SPyNet.edge_fp32 (0 / 1; -1 keeps the model's default): A/B of its cost")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configurations that the default "
                     "(--workload train, one GPU) run appends as `extra_workloads`")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (measured +2 %; the live "
@@ -280,6 +281,8 @@ def main():
     parity_gpu = None
     model = build_model(device, wl)
     model.recompute_chains = bool(args.recompute)
+    if args.spynet_edge_fp32 >= 0:
+        model.spynet.edge_fp32 = bool(args.spynet_edge_fp32)
     model.fp8_chains = bool(args.fp8)
     if args.workload == "infer":
         lrs = synthetic_clip(1, Tn, 180, 320, seed=7 + rank, device=device)

@@ -358,6 +358,15 @@ double vmg_prof_null_interval_us(int reps, void* stream);
 int vmg_morphfc_fwd(int axis, int chunk, const void* x, const void* relu_mask, const void* packed, const float* bias, void* out, void* tok_out,
                     int BT, int H, int W, int C, int Cp, int cout_tiles, int relu, float in_scale, float out_scale, void* stream);
 int64_t vmg_morphfc_token_rows(int axis, int chunk, int BT, int H, int W);
+/* General MorphFC path (any chunk / Cp, bf16 and fp32; the full configuration's chunk 12, Cp 224 / 228 / 448 -- models/function.py:749-750,
+ * 763-764, 772, 776-777, 785): the token matrix of the reference's pad + rearrange chain written by ONE gather kernel, and turned back into the
+ * feature map (cropped) by ONE scatter kernel; the Linear in between is vmg_conv_fwd (ks = 1).  x / out: (BT, H, W, C) channels-last; tok:
+ * (vmg_morph_token_rows(...), ld) with ld >= Cp (features [Cp, ld) are written as zeros: ld = Cp rounded up to 8 serves the convolution
+ * kernel's 16-byte vectors).  Row (group, k) feature p*S + s <-> pixel (position p of the group), channel k*S + s, S = Cp / chunk; groups in the
+ * order (bt, line, group along the mixed axis).  The two calls are each other's adjoint, i.e. each other's backward. */
+int64_t vmg_morph_token_rows(int axis, int chunk, int BT, int H, int W);
+int vmg_morph_tokens_gather(int dtype, int axis, int chunk, const void* x, void* tok, int BT, int H, int W, int C, int Cp, int ld, void* stream);
+int vmg_morph_tokens_scatter(int dtype, int axis, int chunk, const void* tok, void* out, int BT, int H, int W, int C, int Cp, int ld, void* stream);
 
 /* ---- 3-D shifted-window attention (reference: models/swin_3d.py:167-252 rWindowAttention.attention, :55-118 window partition / mask, :772-832 block) ----
  * q (B, D, H, W, C) and kv (B, D, H, W, 2C; k then v) are the outputs of the q / kv Linears on the UN-partitioned feature map; window partition

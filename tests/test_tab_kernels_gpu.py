@@ -207,3 +207,65 @@ def test_drop_path_plan_matches_per_call_semantics():
     FH.residual_drop_path(res, y, 0.3, True, 1.0)  # not the recorded first call: per-call path, still valid
     assert FH.DROP.g is None
     FH.DROP.begin(res.device, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("axis", ["h", "w"])
+@pytest.mark.parametrize("geom", [(1, 2, 16, 16, 224, 12, 228), (1, 3, 32, 32, 224, 16, 224), (2, 1, 8, 8, 448, 8, 448), (1, 2, 10, 7, 40, 4, 44), (1, 1, 5, 9, 16, 3, 18)])
+def test_morph_token_gather_scatter_general_path(dtype, axis, geom):
+    """The general MorphFC path's two kernels (round 4; the full configuration's chunk 16 / 12 / 8 with Cp 224 / 228 / 448, models/function.py:
+    749-750, 763-764, 772, 776-777, 785) against the torch spelling of the reference's pad + rearrange chain (functional.morph_tokens /
+    morph_untokens): bit-exact both ways, zero features up to the padded row length, scatter(gather(x)) == x, and <gather(x), t> == <x, scatter(t)>
+    (they are each other's backward)."""
+    from oracle import recipe as R
+    from vmg_amd import functional as FH, kernels as K
+    B, T, H, W, C, chunk, Cp = geom
+    x = R.seeded((B, T, H, W, C), 1200).to(dtype).cuda()
+    want = FH.morph_tokens(x, axis, chunk, Cp).reshape(-1, Cp)
+    ld = (Cp + 7) // 8 * 8
+    got = K.morph_tokens_gather(x, axis, chunk, Cp, ld)
+    assert got.shape == (want.shape[0], ld)
+    assert torch.equal(got[:, :Cp], want)
+    assert ld == Cp or float(got[:, Cp:].abs().max()) == 0.0
+    t = R.seeded(tuple(want.shape), 1201).to(dtype).cuda()
+    back = K.morph_tokens_scatter(t, axis, chunk, Cp, (B, T, H, W, C))
+    G = want.shape[0] // chunk // (B * T)
+    assert torch.equal(back, FH.morph_untokens(t.reshape(B, T, G, chunk, Cp), axis, chunk, Cp, H, W, C))
+    assert torch.equal(K.morph_tokens_scatter(got, axis, chunk, Cp, (B, T, H, W, C)), x)      # row stride ld, the zero features ignored
+    a = float((got[:, :Cp].double() * t.double()).sum())
+    b = float((x.double() * back.double()).sum())
+    assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(1, 2, 16, 16, 224, 12, 228), (1, 2, 32, 32, 224, 16, 224), (1, 2, 8, 8, 448, 8, 448)])
+def test_morph_linear_general_path_equals_the_torch_spelling(dtype, geom):
+    """functional.morph_linear on the shapes the fused kernel does not cover: output, input gradient and parameter gradients equal the same branch
+    spelled with torch copies around the same Linear kernel (what round 3 ran), bit for bit in the forward (the Linear sees the same token matrix)
+    and within rounding of the reductions in the backward."""
+    from oracle import recipe as R
+    from vmg_amd import functional as FH
+    from vmg_amd import hip
+    B, T, H, W, C, chunk, Cp = geom
+    res = []
+    for general in (True, False):
+        x = R.seeded((B, T, H, W, C), 1210).to(dtype).cuda().requires_grad_(True)
+        w = torch.nn.Parameter(R.seeded((Cp, Cp), 1211, Cp ** -0.5).cuda())
+        b = torch.nn.Parameter(R.seeded((Cp,), 1212, 0.1).cuda())
+        outs = []
+        for axis in ("h", "w"):
+            if general:
+                assert not FH.K.morph_fused_ok(x, chunk, Cp)
+                y = FH.morph_linear(x, w, b, axis, chunk, Cp)
+            else:
+                tk = FH.morph_tokens(x, axis, chunk, Cp)
+                y = FH.morph_untokens(FH.linear(tk, w, b, act=hip.ACT_RELU, alpha=1.0 / Cp), axis, chunk, Cp, H, W, C)
+            outs.append(y)
+        g = R.seeded((B, T, H, W, C), 1213).to(dtype).cuda()
+        (outs[0] * g).sum().add((outs[1] * g.flip(2)).sum()).backward()
+        res.append(([o.detach() for o in outs], x.grad, w.grad, b.grad))
+    for a, bb in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, bb)
+    for i in (1, 2, 3):
+        a, bb = res[0][i].float(), res[1][i].float()
+        assert float((a - bb).abs().max()) <= 1e-5 * max(1.0, float(bb.abs().max())) if dtype == torch.float32 else float((a - bb).abs().max()) <= 2e-2 * float(bb.abs().max())

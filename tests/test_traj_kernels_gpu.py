@@ -166,3 +166,28 @@ def test_pair_frames_is_transpose_flip_cat_and_its_gradient(dtype, n, t):
     else:
         ref = (go.float()[:, :n].flip(0) + go.float()[:, n:]).transpose(0, 1)  # the exact sum, rounded once
         assert torch.equal(x.grad, ref.to(dtype))
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 1, 2), (2, 2, 2, 2), (2, 5, 3, 2), (4, 16, 16, 2), (1, 32, 20, 4)])
+def test_flow_upsampling_x2_align_corners_fwd_bwd(shape):
+    """SPyNet's flow between pyramid levels (models/vmg.py:97-102): scale * F.interpolate(flow, scale_factor=2, mode='bilinear',
+    align_corners=True), and its adjoint.  The backward is a gather (round 4: no zero-fill, no atomics): equal to torch's autograd within fp32
+    rounding AND the same bits on every call, whatever the output buffer held before (a 1x1 map and odd sizes included)."""
+    import torch.nn.functional as F
+    from oracle import recipe as R
+    from vmg_amd import kernels as K
+    n, h, w, c = shape
+    x = R.seeded(shape, 910).cuda()
+    g = R.seeded((n, 2 * h, 2 * w, c), 911).cuda()
+    xr = x.clone().permute(0, 3, 1, 2).requires_grad_(True)
+    want = 2.0 * F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+    want.backward(g.permute(0, 3, 1, 2))
+    got = K.upsample2x_ac(x, 2.0)
+    assert float((got - want.detach().permute(0, 2, 3, 1)).abs().max()) <= 1e-5
+    # poison the allocator's free blocks: the backward must not depend on what its output buffer held
+    junk = [torch.full((n * h * w * c,), float("nan"), device="cuda") for _ in range(16)]
+    del junk
+    dx = K.upsample2x_ac(g, 2.0, backward=True)
+    assert torch.isfinite(dx).all()
+    assert float((dx - xr.grad.permute(0, 2, 3, 1)).abs().max()) <= 1e-5 * max(1.0, float(xr.grad.abs().max()))
+    assert torch.equal(dx, K.upsample2x_ac(g, 2.0, backward=True))

@@ -33,9 +33,11 @@ nmax = max(float(v.grad.norm()) for v in osd.values() if v.grad is not None)
 print(f"{which} B={B}: oracle loss {oloss:.6g}; SPyNet tensors with norm >= 1e-3 of the largest: "
       f"{sum(1 for k in spy if float(osd[k].grad.norm()) >= 1e-3 * nmax)} of {len(spy)}")
 FH.set_wgrad_mode("deferred")
-for net_dt, spy_dt in ((torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16), (torch.float32, torch.float32)):
+for net_dt, spy_dt, edge in ((torch.bfloat16, torch.bfloat16, False), (torch.bfloat16, torch.float32, False), (torch.float32, torch.bfloat16, False),
+                             (torch.float32, torch.float32, False), (torch.bfloat16, torch.bfloat16, True), (torch.float32, torch.bfloat16, True)):
     m = build_product(cfg, net_dt)
     m.spynet_dtype = spy_dt
+    m.spynet.edge_fp32 = edge
     m.load_state_dict(sd)
     m.train()
     out = m(x.cuda())
@@ -52,6 +54,6 @@ for net_dt, spy_dt in ((torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.
         rows.append((float((p.grad.float().cpu().double() - w).norm() / w.norm()), k))
     rows.sort(reverse=True)
     v = [r[0] for r in rows]
-    print(f"net {str(net_dt)[6:]:9s} SPyNet {str(spy_dt)[6:]:9s}: loss {float(loss):.6g}  SPyNet gradient rel L2: max {v[0]:.4f} median {v[len(v) // 2]:.4f}   worst: "
+    print(f"net {str(net_dt)[6:]:9s} SPyNet {str(spy_dt)[6:]:9s}{' + fp32 edges' if edge else '            '}: loss {float(loss):.6g}  SPyNet gradient rel L2: max {v[0]:.4f} median {v[len(v) // 2]:.4f}   worst: "
           + ", ".join(f"{k[7:]} {e:.3f}" for e, k in rows[:4]))
     del m, out, loss

@@ -245,7 +245,106 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void morph_linear_kernel(const Mo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// General path (any chunk / Cp, bf16 and fp32): the token matrix IS materialised, but by one gather kernel (and turned back by one scatter
+// kernel) instead of torch's pad + transpose + reshape + permute + contiguous chain -- the full configuration's stages 1..3 (chunk 16 / 12 /
+// 8 with Cp = 224 / 228 / 448, models/function.py:743-805) run 7 x 32^2 .. 7 x 8^2 pixels: launch count, not bandwidth, is what they cost.
+// Token (group, k), feature f = p*S + s  <->  pixel (position p of the group), channel k*S + s; S = Cp / chunk.  The two kernels are each
+// other's adjoint (every feature-map element appears in exactly one token feature; padding positions / channels read as zero and are
+// dropped on the way back), so each is also the other's backward.
+struct TokGeo {
+  int BT, H, W, C, Cp, ld, chunk, S, axis, gpl;  // ld: row length of the token matrix in elements (>= Cp: zero-filled up to a multiple of 8)
+  long long ngroups;
+};
+__device__ __forceinline__ long long tok_pixel(const TokGeo& g, long long group, int p, bool& inside) {
+  const unsigned gi = (unsigned)(group % g.gpl);
+  const long long r = group / g.gpl;
+  const int lines = g.axis == 0 ? g.W : g.H;
+  const int line = (int)(r % lines);
+  const long long bt = r / lines;
+  const int pos = (int)gi * g.chunk + p;
+  inside = pos < (g.axis == 0 ? g.H : g.W);
+  return g.axis == 0 ? (bt * g.H + pos) * g.W + line : (bt * g.H + line) * g.W + pos;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void morph_gather_kernel(const T* __restrict__ x, T* __restrict__ tok, const TokGeo g) {
+  const long long total = g.ngroups * g.chunk * g.ld;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % g.ld);
+    const long long row = i / g.ld;
+    const int k = (int)(row % g.chunk);
+    const long long group = row / g.chunk;
+    T v = from_f32<T>(0.f);
+    if (f < g.Cp) {
+      const int p = f / g.S, c = k * g.S + (f - p * g.S);
+      bool inside;
+      const long long pix = tok_pixel(g, group, p, inside);
+      if (inside && c < g.C) v = x[pix * g.C + c];
+    }
+    tok[i] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void morph_scatter_kernel(const T* __restrict__ tok, T* __restrict__ out, const TokGeo g) {
+  const long long total = (long long)g.BT * g.H * g.W * g.C;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % g.C);
+    const long long pix = i / g.C;
+    const int xw = (int)(pix % g.W);
+    const long long r = pix / g.W;
+    const int yh = (int)(r % g.H);
+    const long long bt = r / g.H;
+    const int pos = g.axis == 0 ? yh : xw, line = g.axis == 0 ? xw : yh, lines = g.axis == 0 ? g.W : g.H;
+    const int gi = pos / g.chunk, p = pos - gi * g.chunk;
+    const int k = c / g.S, sc = c - k * g.S;
+    const long long group = (bt * lines + line) * g.gpl + gi;
+    out[i] = tok[(group * g.chunk + k) * g.ld + p * g.S + sc];
+  }
+}
+
 }  // namespace
+
+static int tok_geo(TokGeo& g, int axis, int chunk, int BT, int H, int W, int C, int Cp, int ld) {
+  VMG_CHECK(axis == 0 || axis == 1, "morph tokens: axis 0 (H) or 1 (W)");
+  VMG_CHECK(BT > 0 && H > 0 && W > 0 && C > 0 && chunk > 0 && Cp >= C && Cp % chunk == 0 && ld >= Cp, "morph tokens: bad geometry (Cp >= C, chunk | Cp, ld >= Cp)");
+  g.BT = BT; g.H = H; g.W = W; g.C = C; g.Cp = Cp; g.ld = ld; g.chunk = chunk; g.S = Cp / chunk; g.axis = axis;
+  g.gpl = cdiv(axis == 0 ? H : W, chunk);
+  g.ngroups = (long long)BT * (axis == 0 ? W : H) * g.gpl;
+  return 0;
+}
+
+extern "C" int64_t vmg_morph_token_rows(int axis, int chunk, int BT, int H, int W) {
+  if (chunk <= 0 || BT <= 0 || H <= 0 || W <= 0 || (axis != 0 && axis != 1)) return -1;
+  return (int64_t)BT * (axis == 0 ? W : H) * cdiv(axis == 0 ? H : W, chunk) * chunk;
+}
+
+extern "C" int vmg_morph_tokens_gather(int dtype, int axis, int chunk, const void* x, void* tok, int BT, int H, int W, int C, int Cp, int ld, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "morph_tokens_gather: bad dtype");
+  VMG_CHECK(x && tok, "morph_tokens_gather: null pointer");
+  TokGeo g;
+  if (int rc = tok_geo(g, axis, chunk, BT, H, W, C, Cp, ld)) return rc;
+  const long long total = g.ngroups * chunk * ld;
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)tok, g);
+  else hipLaunchKernelGGL(morph_gather_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)tok, g);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_morph_tokens_scatter(int dtype, int axis, int chunk, const void* tok, void* out, int BT, int H, int W, int C, int Cp, int ld, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "morph_tokens_scatter: bad dtype");
+  VMG_CHECK(tok && out, "morph_tokens_scatter: null pointer");
+  TokGeo g;
+  if (int rc = tok_geo(g, axis, chunk, BT, H, W, C, Cp, ld)) return rc;
+  const long long total = (long long)BT * H * W * C;
+  const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_scatter_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)tok, (bf16*)out, g);
+  else hipLaunchKernelGGL(morph_scatter_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)tok, (float*)out, g);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
 
 // the stage stride vmg_conv_pack uses for ks = 1 (conv_igemm.hip: stage_stride(1, ntb, 16))
 static int morph_stage_stride(int nct) { return (2 * 4 * nct * 16 * 16 + 4095) / 4096 * 4096; }

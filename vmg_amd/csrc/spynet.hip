@@ -32,9 +32,8 @@ __device__ __forceinline__ void ac_src(int dst, float ratio, int in, int& i0, in
   l1 = s - (float)i0;
 }
 
-template <bool BWD>
 __global__ void upsample2x_ac_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, float scale) {
-  // FWD: dst (n, 2h, 2w, c) = scale * bilinear_ac(src (n, h, w, c));  BWD: dst (n, h, w, c) += scale * U^T src (n, 2h, 2w, c)
+  // dst (n, 2h, 2w, c) = scale * bilinear_ac(src (n, h, w, c))
   const int ho = 2 * h, wo = 2 * w;
   const float rh = h > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f, rw = w > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
   const long long total = (long long)n * ho * wo * c;
@@ -51,17 +50,57 @@ __global__ void upsample2x_ac_kernel(const float* __restrict__ src, float* __res
     ac_src(xo, rw, w, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const long long b = nn * h;
-    if (!BWD) {
-      const float v = hy * (hx * src[((b + y0) * w + x0) * c + cc] + lx * src[((b + y0) * w + x1) * c + cc]) +
-                      ly * (hx * src[((b + y1) * w + x0) * c + cc] + lx * src[((b + y1) * w + x1) * c + cc]);
-      dst[i] = scale * v;
-    } else {
-      const float g = scale * src[i];
-      atomicAdd(&dst[((b + y0) * w + x0) * c + cc], g * hy * hx);
-      atomicAdd(&dst[((b + y0) * w + x1) * c + cc], g * hy * lx);
-      atomicAdd(&dst[((b + y1) * w + x0) * c + cc], g * ly * hx);
-      atomicAdd(&dst[((b + y1) * w + x1) * c + cc], g * ly * lx);
+    const float v = hy * (hx * src[((b + y0) * w + x0) * c + cc] + lx * src[((b + y0) * w + x1) * c + cc]) +
+                    ly * (hx * src[((b + y1) * w + x0) * c + cc] + lx * src[((b + y1) * w + x1) * c + cc]);
+    dst[i] = scale * v;
+  }
+}
+
+// The adjoint as a GATHER: dst (n, h, w, c) = scale * U^T src (n, 2h, 2w, c) -- input pixel (y, x) collects, in a fixed order, from the few
+// output pixels whose interpolation touches it.  No atomics (bit-reproducible) and no zero-fill: round 3's version was hipMemsetAsync +
+// float atomics, and the memset NODE that a stream capture records for it did not clear buffers of a few KB on replay (SPyNet's coarse
+// pyramid levels accumulated onto whatever the graph's pool had left there: NaN gradients in a replayed step, tools/dbg/replay_stress2.py).
+// Output row yo touches input rows y0 = floor(yo * r) and y0 + 1, so the candidates for input row y are the yo with yo * r in (y - 1, y + 1).
+__device__ __forceinline__ void ac_range(int i, float ratio, int in, int out, int& lo, int& hi) {
+  if (in <= 1 || ratio <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf((float)(i - 1) / ratio) - 1;
+  hi = (int)ceilf((float)(i + 1) / ratio) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+}
+__device__ __forceinline__ float ac_weight(int dst, float ratio, int in, int i) {  // weight of input index i in output index dst
+  int i0, i1;
+  float l1;
+  ac_src(dst, ratio, in, i0, i1, l1);
+  return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+__global__ void upsample2x_ac_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, float scale) {
+  const int ho = 2 * h, wo = 2 * w;
+  const float rh = h > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f, rw = w > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+  const long long total = (long long)n * h * w * c;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c);
+    long long t = i / c;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const long long nn = t / h;
+    int ylo, yhi, xlo, xhi;
+    ac_range(y, rh, h, ho, ylo, yhi);
+    ac_range(x, rw, w, wo, xlo, xhi);
+    float acc = 0.f;
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      const float wy = ac_weight(yo, rh, h, y);
+      if (wy == 0.f) continue;
+      const float* row = src + ((nn * ho + yo) * wo) * (long long)c + cc;
+      float racc = 0.f;
+      for (int xo = xlo; xo <= xhi; ++xo) {
+        const float wx = ac_weight(xo, rw, w, x);
+        if (wx != 0.f) racc += wx * row[(long long)xo * c];
+      }
+      acc += wy * racc;
     }
+    dst[i] = scale * acc;
   }
 }
 
@@ -84,20 +123,15 @@ extern "C" int vmg_avgpool2_nhwc(int dtype, const void* x, void* y, int n, int h
 extern "C" int vmg_upsample2x_ac_fwd(const float* x, float* y, int n, int h, int w, int c, float scale, void* stream) {
   VMG_CHECK(x && y && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x_fwd: bad arguments");
   const long long total = (long long)n * 4 * h * w * c;
-  hipLaunchKernelGGL(upsample2x_ac_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, h, w, c, scale);
+  hipLaunchKernelGGL(upsample2x_ac_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, n, h, w, c, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmg_upsample2x_ac_bwd(const float* dy, float* dx, int n, int h, int w, int c, float scale, void* stream) {
   VMG_CHECK(dy && dx && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x_bwd: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dx, 0, (size_t)n * h * w * c * sizeof(float), st) != hipSuccess) {
-    vmg_set_error("upsample2x_bwd: memset failed");
-    return -2;
-  }
-  const long long total = (long long)n * 4 * h * w * c;
-  hipLaunchKernelGGL(upsample2x_ac_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, st, dy, dx, n, h, w, c, scale);
+  const long long total = (long long)n * h * w * c;
+  hipLaunchKernelGGL(upsample2x_ac_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, h, w, c, scale);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -227,6 +227,9 @@ def _pad_channels(t: torch.Tensor, mult: int = 8) -> torch.Tensor:
     c = t.shape[-1]
     if c % mult == 0:
         return t
+    base = getattr(t, "_vmg_padded", None)  # a channel slice of a tensor that already carries the zero channels (functional._MorphGather)
+    if base is not None and base.shape[-1] == _pad_to(c, mult):
+        return base
     return torch.nn.functional.pad(t, (0, _pad_to(c, mult) - c))
 
 
@@ -1137,15 +1140,48 @@ class _MorphLinear(_Fn):
         return dx, d_w, d_b, None, None, None
 
 
+class _MorphGather(_Fn):
+    """x (B,T,H,W,C) -> token matrix (rows, ld) by ONE gather kernel (the reference's pad + rearrange chain, models/function.py:749-750,
+    763-764, 776-777); ld = Cp rounded up to 8, features [Cp, ld) are zeros (the convolution kernel reads 16-byte vectors).  Backward = the
+    scatter kernel (the two are each other's adjoint)."""
+
+    @staticmethod
+    def forward(ctx, x, axis, chunk, Cp):
+        x = x.contiguous()
+        ctx.cfg = (axis, chunk, Cp, tuple(x.shape))
+        return K.morph_tokens_gather(x, axis, chunk, Cp, _pad_to(Cp))
+
+    @staticmethod
+    def backward(ctx, g):
+        axis, chunk, Cp, shape = ctx.cfg
+        return K.morph_tokens_scatter(g.contiguous(), axis, chunk, Cp, shape), None, None, None
+
+
+class _MorphScatter(_Fn):
+    """token matrix (rows, Cp) -> (B,T,H,W,C) by ONE scatter kernel (inverse layout + crop, models/function.py:772, 785); backward = the gather."""
+
+    @staticmethod
+    def forward(ctx, tok, axis, chunk, Cp, shape):
+        ctx.cfg = (axis, chunk, Cp, tuple(shape))
+        return K.morph_tokens_scatter(tok.contiguous(), axis, chunk, Cp, shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        axis, chunk, Cp, shape = ctx.cfg
+        return K.morph_tokens_gather(g.contiguous(), axis, chunk, Cp, Cp), None, None, None, None
+
+
 def morph_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], axis: str, chunk: int, Cp: int) -> torch.Tensor:
-    """relu(Linear(tokens)) / Cp of one MorphFC branch on (B,T,H,W,C).  Fused kernel where it is instantiated; the general path gathers the
-    tokens, runs the Linear kernel and scatters back."""
-    B, T, H, W, C = x.shape
+    """relu(Linear(tokens)) / Cp of one MorphFC branch on (B,T,H,W,C).  Fused kernel where it is instantiated (stage 0 of both shipped
+    configurations); the general path -- any chunk / Cp, fp32 too -- is gather kernel + Linear kernel + scatter kernel."""
     if K.morph_fused_ok(x, chunk, Cp):
         return _MorphLinear.apply(x, weight, bias, axis, chunk, Cp)
-    t = morph_tokens(x, axis, chunk, Cp)
-    t = linear(t, weight, bias, act=hip.ACT_RELU, alpha=1.0 / Cp)
-    return morph_untokens(t, axis, chunk, Cp, H, W, C)
+    tok = _MorphGather.apply(x, axis, chunk, Cp)
+    if tok.shape[-1] != Cp:  # (Cp = 228: the Linear takes the Cp real features; its kernel reads the zero-padded matrix they are a slice of)
+        padded, tok = tok, tok[:, :Cp]
+        tok._vmg_padded = padded
+    t = linear(tok, weight, bias, act=hip.ACT_RELU, alpha=1.0 / Cp)
+    return _MorphScatter.apply(t, axis, chunk, Cp, tuple(x.shape))
 
 
 class _ChannelAttention(_Fn):

@@ -96,6 +96,9 @@ SIGNATURES = {
     "vmg_morphfc_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                 c_void_p]),
     "vmg_morphfc_token_rows": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "vmg_morph_token_rows": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "vmg_morph_tokens_gather": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_morph_tokens_scatter": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_win3d_attn_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_void_p]),
     "vmg_win3d_attn_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

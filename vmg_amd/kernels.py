@@ -482,6 +482,36 @@ def morphfc_forward(x: torch.Tensor, axis: str, chunk: int, Cp: int, pw: PackedC
     return out, tok
 
 
+def morph_tokens_gather(x: torch.Tensor, axis: str, chunk: int, Cp: int, ld: Optional[int] = None) -> torch.Tensor:
+    """x (B,T,H,W,C) contiguous -> the MorphFC token matrix (rows, ld) of the reference's pad + rearrange chain (vmg_morph_tokens_gather): row
+    (group, k), feature p*S + s = x[position p of the group, channel k*S + s], zeros for padding positions / channels and for features >= Cp."""
+    hip.require_cuda(x)
+    B, T, H, W, C = x.shape
+    if not x.is_contiguous():
+        raise HipError("morph_tokens_gather: contiguous (B,T,H,W,C) expected")
+    ld = Cp if ld is None else ld
+    ax = 0 if axis == "h" else 1
+    rows = hip.lib().vmg_morph_token_rows(ax, chunk, B * T, H, W)
+    tok = torch.empty((rows, ld), dtype=x.dtype, device=x.device)
+    hip.check(hip.lib().vmg_morph_tokens_gather(hip.dtype_code(x.dtype), ax, chunk, x.data_ptr(), tok.data_ptr(), B * T, H, W, C, Cp, ld, hip.stream_ptr()),
+              "vmg_morph_tokens_gather")
+    return tok
+
+
+def morph_tokens_scatter(tok: torch.Tensor, axis: str, chunk: int, Cp: int, shape) -> torch.Tensor:
+    """The inverse layout + crop: tok (rows, ld >= Cp), row stride ld -> (B,T,H,W,C) (vmg_morph_tokens_scatter)."""
+    hip.require_cuda(tok)
+    B, T, H, W, C = shape
+    ax = 0 if axis == "h" else 1
+    rows = hip.lib().vmg_morph_token_rows(ax, chunk, B * T, H, W)
+    if tok.dim() != 2 or tok.shape[0] != rows or tok.shape[1] < Cp or tok.stride(1) != 1:
+        raise HipError(f"morph_tokens_scatter: token matrix ({rows}, >= {Cp}) expected, got {tuple(tok.shape)}")
+    out = torch.empty((B, T, H, W, C), dtype=tok.dtype, device=tok.device)
+    hip.check(hip.lib().vmg_morph_tokens_scatter(hip.dtype_code(tok.dtype), ax, chunk, tok.data_ptr(), out.data_ptr(), B * T, H, W, C, Cp, tok.stride(0),
+                                                 hip.stream_ptr()), "vmg_morph_tokens_scatter")
+    return out
+
+
 def _win3d_geom(q, kv, table, heads, wt):
     B, D, H, W, C = q.shape
     if tuple(kv.shape) != (B, D, H, W, 2 * C) or kv.dtype != q.dtype or not q.is_contiguous() or not kv.is_contiguous():

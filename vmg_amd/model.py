@@ -70,11 +70,18 @@ class SPyNetBasicModule(nn.Module):
         self.basic_module = nn.Sequential(_ConvModule(8, 32, True), _ConvModule(32, 64, True), _ConvModule(64, 32, True),
                                           _ConvModule(32, 16, True), _ConvModule(16, 2, False))
 
-    def forward(self, srcs: Sequence[torch.Tensor]) -> torch.Tensor:
-        """srcs: channels-last tensors whose channels concatenate to the 8 input channels [ref, warped, flow] -> (n,h,w,2)."""
+    def forward(self, srcs: Sequence[torch.Tensor], inner_dtype=None) -> torch.Tensor:
+        """srcs: channels-last tensors whose channels concatenate to the 8 input channels [ref, warped, flow] -> (n,h,w,2).
+        inner_dtype: the three middle convolutions (32 -> 64 -> 32 -> 16, 94 % of the module's FLOPs) compute in this dtype while the first and
+        the last one -- the two that touch the flow -- keep the dtype of `srcs` (SPyNet.edge_fp32)."""
         n, h, w = srcs[0].shape[:3]
         y = list(srcs)
-        for m in self.basic_module:
+        last = len(self.basic_module) - 1
+        for i, m in enumerate(self.basic_module):
+            if inner_dtype is not None and i == 1:
+                y = [y[0].to(inner_dtype)]
+            if inner_dtype is not None and i == last:
+                y = [y[0].to(srcs[0].dtype)]
             y = [FH.conv2d(y, m.conv.weight, m.conv.bias, n, h, w, ks=7, act=ACT_RELU if m.act else hip.ACT_NONE)]
         return y[0]
 
@@ -95,12 +102,19 @@ class SPyNet(nn.Module):
             raise TypeError(f"[pretrained] should be str or None, but got {type(pretrained)}.")
         self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
         self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+        # bf16 runs: everything that touches the 2-channel flow -- the warp of the support frame, the 8-channel operand [ref, warped, flow], the
+        # first convolution (8 -> 32: its data gradient IS the flow gradient of the level below) and the last one (16 -> 2: its output is the
+        # flow residual, its output gradient the flow gradient) -- stays fp32; only the three middle convolutions run in bf16.
+        self.edge_fp32 = False
 
     def compute_flow(self, ref: torch.Tensor, supp: torch.Tensor) -> torch.Tensor:
         """ref, supp: channels-last (n,h,w,8) in the compute dtype, normalised RGB in channels 0..2 and zeros behind (the warp
         kernel moves 16-byte channel vectors), h and w multiples of 32 -> flow (n,h,w,2) fp32 (models/vmg.py:39-85)."""
         from . import kernels as K
         n, h, w, _ = ref.shape
+        inner = None
+        if self.edge_fp32 and ref.dtype != torch.float32:
+            inner, ref, supp = ref.dtype, ref.float(), supp.float()
         dt = ref.dtype
         refs, supps = [ref], [supp]
         with torch.no_grad():  # the pyramid of the input frames needs no gradient
@@ -115,7 +129,7 @@ class SPyNet(nn.Module):
             # one 8-channel operand [ref, warped, flow] (a 16-byte vector per pixel) instead of a virtual concat of 3 + 3 + 2 channels:
             # the convolution and its weight gradient then move whole vectors
             x8 = torch.cat([refs[level][..., :3], warped[..., :3], up.to(dt)], -1)
-            res = self.basic_module[level]([x8])
+            res = self.basic_module[level]([x8], inner)
             flow = up + res.float()
         return flow
 
