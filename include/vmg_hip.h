@@ -219,6 +219,10 @@ int vmg_conv_wgrad_batched_ws(int dtype, int ks, int npairs, const void* const* 
 int vmg_conv_wgrad3_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin,
                           int64_t dy_ps, int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws,
                           int64_t ws_bytes, void* stream);
+/* Tuning knob (A/B measurements, tests): which kernel serves the batched 3x3 weight gradients -- 1 (default) conv_wgrad3b_kernel, whose tile
+ * copies are buffer loads with constant per-lane offsets issued between the MFMA columns; 0 conv_wgrad3_kernel (round 2: per-lane 64-bit pointers,
+ * the copies as one block per unit).  Same tiles, same slab order, same bits.  Returns the previous value; any other argument only queries. */
+int vmg_conv_wgrad3_variant(int variant);
 /* The same for 1x1 convolutions / Linears (bf16; Cin, Cout and the pixel strides multiples of 8; at least 2 048 pixels per problem): x / dy
  * hold nprob * npairs pointers over M pixels each, dW (O_total, I_total). */
 int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const void* const* dy, int64_t M, int64_t x_ps, int Cin, int64_t dy_ps,

@@ -698,3 +698,33 @@ def test_linear_wgrad2_multi_equals_single_launches():
         assert float((dW - dW1).abs().max()) <= 1e-4 * max(1.0, float(dW1.abs().max())), f"problem {i}"
         if db is not None:
             assert float((db - db1).abs().max()) <= 1e-4 * max(1.0, float(db1.abs().max())), f"problem {i} bias"
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 40, 144, 144, 3), (1, 9, 70, 64, 64, 2), (1, 16, 16, 144, 144, 5), (2, 8, 8, 144, 288, 4), (1, 64, 64, 144, 144, 14),
+                                   (1, 5, 33, 112, 112, 2), (3, 1, 64, 48, 144, 1), (2, 20, 36, 3, 144, 2)])
+def test_conv_wgrad3_kernel_variants_give_the_same_bits(shape):
+    """Round 4: conv_wgrad3b_kernel (tile copies as buffer loads with constant per-lane offsets, out-of-image lanes zeroed by the descriptor's
+    range check, the copies issued between the MFMA columns) against conv_wgrad3_kernel (per-lane 64-bit pointers and a zero buffer): the same
+    tiles in the same order into the same slabs -- the gradients must be equal bit for bit, image borders, partial last segments (W = 40, 70, 33,
+    36, 16, 8), partial channel blocks and the 3-channel stem slice included."""
+    hip, K, O, R = _setup()
+    N, H, W, Ci, Co, P = shape
+    dt = torch.bfloat16
+    xd = [R.seeded((N, H, W, Ci), 140 + p).cuda().to(dt) for p in range(P)]
+    dd = [R.seeded((N, H, W, Co), 160 + p).cuda().to(dt) for p in range(P)]
+    if Ci % 8:
+        xd = [F.pad(x, (0, 8 - Ci % 8))[..., :Ci] for x in xd]
+    outs = []
+    lib = hip.lib()
+    prev = lib.vmg_conv_wgrad3_variant(-1)
+    try:
+        for variant in (0, 1):
+            lib.vmg_conv_wgrad3_variant(variant)
+            dW, db = torch.zeros(Co, Ci, 3, 3, device="cuda"), torch.zeros(Co, device="cuda")
+            K.conv_wgrad_batched(xd, dd, dW, db, 3, N, H, W)
+            outs.append((dW.cpu(), db.cpu()))
+    finally:
+        lib.vmg_conv_wgrad3_variant(prev)
+    assert prev == 1
+    assert torch.isfinite(outs[1][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

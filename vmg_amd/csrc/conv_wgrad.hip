@@ -541,6 +541,26 @@ __device__ __forceinline__ bf16x8 tr_read(const char* p0, int rs) {
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int w3_u32x4;
+// LDS-DMA through a buffer resource: 16 bytes per lane from (descriptor base + SGPR offset + per-lane 32-bit offset) into the lane-linear 1 KiB
+// block at lds_dst; a lane whose offset is >= num_records (2^31 here) gets zeros.  Hidden from hipcc's wait bookkeeping like glds16_hidden; the
+// s_nop covers the M0 write and SGPRs the compiler's SALU may have written just before the statement (descriptor, offset).
+__device__ __forceinline__ void bufdma16_hidden(unsigned voff, w3_u32x4 rsrc, unsigned soff, char* lds_dst) {
+  unsigned keep;
+  const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(ldst) : "memory");
+}
+__device__ __forceinline__ w3_u32x4 w3_rsrc(const char* base) {  // raw buffer (stride 0) of 2^31 bytes at `base` (wave-uniform)
+  const unsigned long long p = (unsigned long long)(uintptr_t)base;
+  w3_u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xFFFFu;
+  r[2] = 0x80000000u;
+  r[3] = 0x00020000u;
+  return r;
+}
+
 __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -761,8 +781,221 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3_kernel(const Wgrad2K a
   }
 }
 
+__global__ __launch_bounds__(W3_THREADS) void conv_wgrad3b_kernel(const Wgrad2K a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave >> 2, q = wave & 3;
+  SlabBlock blk = xcd_slab_block(a.gx, a.gy, a.S * a.nprob);
+  const int prob = blk.z / a.S;  // several problems of one shape share the launch: fewer, longer K slabs per problem at a full chip
+  const int zz = blk.z;          // slab index over all problems (the slab workspace is [problem][S]...)
+  blk.z -= prob * a.S;
+  const char* const* xs = a.x + prob * WG_MAX_PAIRS;
+  const char* const* dys = a.dy + prob * WG_MAX_PAIRS;
+  const int ob = blk.x * W2_DYC, ib = blk.y * W2_XC;
+  const long long u_lo = a.U * blk.z / a.S, u_hi = a.U * (blk.z + 1) / a.S;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero_buf);
+
+  f32x4 acc[5][7];
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The bias gradient rides on the tile's PADDING: wave q = 3 owns fragment columns 21..27 of 27, its seventh column is a duplicate that the
+  // reduce kernel drops.  With a ones operand in its place that accumulator column is sum_p dY[p][co] -- no accumulators of its own (20
+  // registers) and no extra MFMAs (round 2's kernel issues five more per unit on the q = 0 waves of the first ci block: 80 instead of 70 on SIMD 0).
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+  const bool bias_col = q == 3;
+
+  // ---- copy instructions (round 4).  conv_wgrad3_kernel above keeps a 64-bit POINTER per lane and copy instruction, selects it against a
+  // zero buffer with per-unit bounds tests and advances it by wave-uniform 64-bit deltas: ~60 instructions per unit and wave, issued as ONE
+  // block before or after the unit's 35 MFMAs -- while a wave is in that block it feeds the matrix pipe nothing (the unit cost MFMAs + block:
+  // 0.92 us where the MFMAs alone take 0.50).  Here the copies are BUFFER loads (`buffer_load_dwordx4 ... offen lds`): the tensor base sits in a
+  // resource descriptor (SGPRs), the unit's first pixel in an SGPR byte offset that advances by precomputed 32-bit deltas, and a lane's offset
+  // inside the [dY | X] list is a CONSTANT 32-bit register.  Which lanes fall outside the image depends on four wave-uniform facts only (first /
+  // last row, first / last segment of a row): a lane carries its static flags, a unit its bits, and a flagged lane asks for offset 2^31 -- beyond
+  // num_records, so the hardware writes zeros.  3 VALU per copy instruction instead of ~12, no zero buffer, no 64-bit lane arithmetic; and the
+  // issue block of a unit shrinks from ~60 to ~25 instructions.
+  unsigned voff[W3_SLOTS], flg[W3_SLOTS];
+  const int nun = (int)(u_hi - u_lo);
+  int ipair = (int)(u_lo / a.Upair), iseg, iy, in_;
+  {
+    const long long uu = u_lo - (long long)ipair * a.Upair;
+    iseg = (int)(uu % a.SEG);
+    const long long r = uu / a.SEG;
+    iy = (int)(r % a.H);
+    in_ = (int)(r / a.H);
+  }
+  const int wlast = a.W - (a.SEG - 1) * 32;  // pixels of a row's last segment
+#pragma unroll
+  for (int sl = 0; sl < W3_SLOTS; ++sl) {
+    const int L = (sl * W3_WAVES + wave) * 64 + lane;
+    if (L < W3_DYV) {
+      const int pp = L / 18, v = L - pp * 18;
+      voff[sl] = (unsigned)((pp * a.dy_ps + ob + v * 8) * 2);
+      flg[sl] = 32u | (pp >= wlast ? 8u : 0u) | ((ob + v * 8 + 8 <= a.Cout) ? 0u : 16u);
+    } else if (L < W3_VECS) {
+      const int vec = L - W3_DYV, pp = vec / 6, v = vec - pp * 6;
+      const int rr = pp / W2_XW, col = pp - rr * W2_XW;
+      voff[sl] = (unsigned)(((long long)(rr * a.W + col) * a.x_ps + ib + v * 8) * 2);  // from the descriptor's base = one row and one pixel before the unit
+      flg[sl] = 32u | (rr == 0 ? 1u : 0u) | (rr == 2 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col - 1 >= wlast ? 8u : 0u) | ((ib + v * 8 + 8 <= a.Cin) ? 0u : 16u);
+    } else {
+      voff[sl] = 0u;
+      flg[sl] = 48u;
+    }
+  }
+  const long long halo_x = (long long)(a.W + 1) * a.x_ps * 2;
+  w3_u32x4 rs_dy = w3_rsrc(dys[ipair]), rs_x = w3_rsrc(xs[ipair] - halo_x);
+  unsigned soff_dy, soff_x;
+  {
+    const long long row0 = ((long long)in_ * a.H + iy) * a.W + iseg * 32;
+    soff_dy = (unsigned)(row0 * a.dy_ps * 2);
+    soff_x = (unsigned)(row0 * a.x_ps * 2);
+  }
+  const unsigned a32_dy = (unsigned)(32 * a.dy_ps * 2), a32_x = (unsigned)(32 * a.x_ps * 2);
+  const unsigned arow_dy = (unsigned)(wlast * a.dy_ps * 2), arow_x = (unsigned)(wlast * a.x_ps * 2);  // last segment of a row -> first pixel of the next row
+  // Every copy instruction is UNCONDITIONAL: a unit past the end of the slab is issued as a DUMMY -- bit 32, which every lane carries, is set in
+  // the unit's bits and all 64 lanes ask for offset 2^31 (zeros land in a free slot, no memory is touched).  Every wave then issues exactly six
+  // copies per even iteration and every counted wait is vmcnt(6).
+  unsigned ubits = 0;
+  auto issue_slot = [&](int sl, int buf, unsigned dummy) __attribute__((always_inline)) {
+    if (sl == 0) ubits = dummy | 16u | (iy == 0 ? 1u : 0u) | (iy == a.H - 1 ? 2u : 0u) | (iseg == 0 ? 4u : 0u) | (iseg == a.SEG - 1 ? 8u : 0u);
+    const bool isdy = sl * W3_WAVES + wave < W3_DYV / 64;  // wave-uniform: chunks 0..8 of the list are dY
+    const unsigned vo = (flg[sl] & ubits) ? 0x80000000u : voff[sl];
+    bufdma16_hidden(vo, isdy ? rs_dy : rs_x, isdy ? soff_dy : soff_x, smem + buf * W3_BUF + (sl * W3_WAVES + wave) * 1024);
+  };
+  auto advance = [&]() __attribute__((always_inline)) {  // the odometer: to the unit after the one just issued
+    unsigned d_dy = a32_dy, d_x = a32_x;
+    if (++iseg == a.SEG) {
+      iseg = 0;
+      d_dy = arow_dy; d_x = arow_x;
+      if (++iy == a.H) {
+        iy = 0;
+        if (++in_ == a.N) {
+          in_ = 0;
+          ++ipair;
+          if (ipair < a.npairs) {  // next (x, dy) pair: other tensors, from their pixel 0
+            rs_dy = w3_rsrc(dys[ipair]);
+            rs_x = w3_rsrc(xs[ipair] - halo_x);
+            soff_dy = 0u - d_dy;
+            soff_x = 0u - d_x;
+          }
+        }
+      }
+    }
+    soff_dy += d_dy;
+    soff_x += d_x;
+  };
+  auto issue = [&](int buf, bool live) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < W3_SLOTS; ++sl) issue_slot(sl, buf, live ? 0u : 32u);
+    if (live) advance();
+  };
+
+  // ---- fragment addresses (within a buffer): dY rows are 288 B, X rows 96 B; lane i = 4qq+pp of a 16-lane group supplies
+  // block row qq, columns 4pp..4pp+3 of a transposed 4x16 block read
+  const int li = lane & 15, lg = lane >> 4;
+  const int a_off = (8 * lg + (li >> 2)) * (W2_DYC * 2) + (h * 5 * 16 + 4 * (li & 3)) * 2;  // + c * 32 for co tile c of this wave
+  int b_off[7];
+#pragma unroll
+  for (int jj = 0; jj < 7; ++jj) {
+    const int col = min(q * 7 + jj, 26), itile = col / 9, tap = col - 9 * itile, ky = tap / 3, kx = tap - 3 * ky;
+    b_off[jj] = W3_DYV * 16 + ky * W2_XW * (W2_XC * 2) + (kx + 8 * lg + (li >> 2)) * (W2_XC * 2) + (itile * 16 + 4 * (li & 3)) * 2;
+  }
+
+  // SIX unit slots, one barrier per TWO units.  Unit j lives in slot j % 6; iteration j multiplies unit j (fragments already in
+  // registers) and reads unit j+1's fragments.  At the barrier of an even j every wave has (a) waited for its share of units
+  // j+1 and j+2 (units j+3, j+4 stay in flight: the wait is counted) and (b) drained its reads of unit j; afterwards units
+  // j+5 and j+6 are issued into the slots of units j-1 and j.
+  for (int j = 0; j < 5; ++j) issue(j, j < nun);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // units 3, 4 (real or dummy) may stay in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 af[5], bfg[7];
+  if (nun > 0) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) af[c] = tr_read(smem + a_off + c * 32, W2_DYC * 2);
+#pragma unroll
+    for (int jj = 0; jj < 7; ++jj) bfg[jj] = tr_read(smem + b_off[jj], W2_XC * 2);
+    if (bias_col) bfg[6] = ones;
+  }
+  // one unit; SU = its slot (compile-time), j = its index.  Returns false when the slab is finished.
+  auto unit = [&](int j, auto su_c) __attribute__((always_inline)) -> bool {
+    constexpr int SU = decltype(su_c)::value, SN = (SU + 1) % 6, S5 = (SU + 5) % 6;
+    constexpr bool SYNC = (SU & 1) == 0;  // slots alternate with the unit index: even units synchronise
+    if (j >= nun) return false;
+    if (SYNC) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // units j + 1, j + 2 have landed; j + 3, j + 4 (real or dummy) stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of unit j are complete
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    const char* src = smem + ((j + 1 < nun) ? SN : SU) * W3_BUF;  // (last unit: re-read its own slot; the values are not used)
+    // units j+5, j+6 -> the slots of units j-1 and j (free since this unit's barrier), as in conv_wgrad3_kernel: h = 0 issues its copies BEFORE
+    // its MFMAs, h = 1 after them.  (Issuing one unit's copies in EVERY iteration, or the copy instructions between the MFMA columns, made hipcc
+    // spill the accumulators -- 3 KB of scratch per lane, 25x slower; the same happens to conv_wgrad3_kernel with that change alone.)
+#ifdef VMG_DIAG
+    const bool nocopy = a.dbg & 1;
+#else
+    constexpr bool nocopy = false;
+#endif
+    if (SYNC && h == 0) {
+      issue(S5, j + 5 < nun && !nocopy);
+      issue(SU, j + 6 < nun && !nocopy);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 7; ++jj) {
+#ifdef VMG_DIAG
+      if (!(a.dbg & 2))
+#endif
+      {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[c][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfg[jj], acc[c][jj], 0, 0, 0);
+      }
+#ifdef VMG_DIAG
+      if (!(a.dbg & 4))
+#endif
+      bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
+      if (jj == 6) {  // (a select, not a branch: wave-uniform condition, four v_cndmask)
+        const bf16x8 rd = bfg[6];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bfg[6][e] = bias_col ? one : rd[e];
+      }
+    }
+#ifdef VMG_DIAG
+    if (!(a.dbg & 4))
+#endif
+    {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) af[c] = tr_read(src + a_off + c * 32, W2_DYC * 2);  // (behind the last MFMA that reads af[c])
+    }
+    if (SYNC && h == 1) {
+      issue(S5, j + 5 < nun && !nocopy);
+      issue(SU, j + 6 < nun && !nocopy);
+    }
+    return true;
+  };
+  for (int base = 0; base < nun; base += 6) {
+    if (!unit(base + 0, std::integral_constant<int, 0>{})) break;
+    if (!unit(base + 1, std::integral_constant<int, 1>{})) break;
+    if (!unit(base + 2, std::integral_constant<int, 2>{})) break;
+    if (!unit(base + 3, std::integral_constant<int, 3>{})) break;
+    if (!unit(base + 4, std::integral_constant<int, 4>{})) break;
+    if (!unit(base + 5, std::integral_constant<int, 5>{})) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // (the dummy copies of the last iterations too: no LDS-DMA outlives the loop)
+  // slab store: native accumulator layout, one float4 per lane per tile (fully coalesced)
+  float* sl = a.slab + ((((long long)zz * a.gy + blk.y) * a.gx + blk.x) * W3_WAVES + wave) * (W3_TILES * 256);
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) *reinterpret_cast<f32x4*>(sl + ((c * 7 + j) * 64 + lane) * 4) = acc[c][j];
+  // (bias: column 6 of the q = 3 waves, see above; slot 35 of the wave's slab stays unused)
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __restrict__ slab0, int S, int gx, int gy, int Cin, int Cout,
-                                                                 const Wgrad3Out outs, int I_total, int o0, int i0) {
+                                                                 const Wgrad3Out outs, int I_total, int o0, int i0, int bias_in_pad) {
   __shared__ float red[256];
   const long long per_s = (long long)gy * gx * W3_WG_FLOATS;
   const float* __restrict__ slab = slab0 + (long long)blockIdx.y * S * per_s;  // blockIdx.y = problem
@@ -792,8 +1025,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_reduce_kernel(const float* __
         const int ci = ciblk * W2_XC + itile * 16 + l15;
         if (co < Cout && ci < Cin) dW[((long long)(o0 + co) * I_total + (i0 + ci)) * 9 + t] += sum * scale;
       }
-    } else if (db && q == 0 && ciblk == 0 && l15 < 5) {
+    } else if (!bias_in_pad && db && q == 0 && ciblk == 0 && l15 < 5) {
       const int cot = h * 5 + l15;
+      const int co = coblk * W2_DYC + cot * 16 + 4 * g + r;
+      if (cot < 9 && co < Cout) db[o0 + co] += sum * scale;
+    }
+    if (bias_in_pad && db && tile < 35 && q == 3 && ciblk == 0 && l15 == 0 && tile % 7 == 6) {  // conv_wgrad3b_kernel: the padding column of the q = 3 waves
+      const int cot = h * 5 + tile / 7;
       const int co = coblk * W2_DYC + cot * 16 + 4 * g + r;
       if (cot < 9 && co < Cout) db[o0 + co] += sum * scale;
     }
@@ -1165,6 +1403,13 @@ int launch_wgrad7(Wgrad7K k, float* dW, int I_total, int o0, int i0, float* db, 
 }  // namespace
 
 // Shared by the single and the multi-problem entry points.  Returns 1 when the workspace cannot hold the slabs (caller falls back).
+static int g_w3_variant = 1;  // 1: conv_wgrad3b_kernel (buffer-addressed copies between the MFMA columns), 0: conv_wgrad3_kernel
+extern "C" int vmg_conv_wgrad3_variant(int v) {
+  const int prev = g_w3_variant;
+  if (v == 0 || v == 1) g_w3_variant = v;
+  return prev;
+}
+
 static int launch_wgrad3(int nprob, int npairs, const void* const* x, const void* const* dy, int N, int H, int W, int64_t x_ps, int Cin, int64_t dy_ps,
                          int Cout, float* const* dW, int I_total, int o0, int i0, float* const* db, const float* scales, void* ws, int64_t ws_bytes,
                          void* stream) {
@@ -1205,11 +1450,24 @@ static int launch_wgrad3(int nprob, int npairs, const void* const* x, const void
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr3[dev3] = true;
   }
-  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)(gx * gy * S * nprob)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
+  // the buffer-addressed variant needs every byte of a pair's tensors (plus the X tile's reach of two rows and 34 pixels) below 2^31 from the base
+  int bias_in_pad = 0;
+  const long long reach = ((long long)N * H * W + 2LL * W + 40) * (x_ps > dy_ps ? x_ps : dy_ps) * 2;
+  if (g_w3_variant == 1 && reach < (1LL << 31)) {
+    static bool attr3b[VMG_MAX_DEVICES] = {};
+    if (!attr3b[dev3]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad3b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr3b[dev3] = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad3b_kernel, dim3((unsigned)(gx * gy * S * nprob)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
+    bias_in_pad = 1;
+  } else {
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)(gx * gy * S * nprob)), dim3(W3_THREADS), 6 * W3_BUF, st, k);
+  }
   VMG_LAUNCH_CHECK();
   const long long per3 = (long long)gy * gx * W3_WG_FLOATS;
   const int rb3 = (int)(cdiv64(per3, 64) > 8192 ? 8192 : cdiv64(per3, 64));
-  hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3, nprob), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, outs, I_total, o0, i0);
+  hipLaunchKernelGGL(conv_wgrad3_reduce_kernel, dim3(rb3, nprob), dim3(256), 0, st, (const float*)ws, (int)S, gx, gy, Cin, Cout, outs, I_total, o0, i0, bias_in_pad);
   VMG_LAUNCH_CHECK();
   return 0;
 }

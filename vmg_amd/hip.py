@@ -105,6 +105,7 @@ SIGNATURES = {
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_conv_wgrad3_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_conv_wgrad3_variant": (c_int, [c_int]),
     "vmg_linear_wgrad2_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_replay_build": (c_void_p, [c_void_p, c_void_p, c_void_p]),
