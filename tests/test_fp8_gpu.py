@@ -177,3 +177,41 @@ def test_few_levels_model_with_fp8_chains():
     print(f"PSNR vs the fp32 oracle: fp8 chains {p8:.2f} dB, bf16 {p16:.2f} dB; |PSNR(hip, target) - PSNR(oracle, target)| = {abs(psnr(outs[True], tgt) - psnr(want, tgt)):.4f} dB")
     assert p8 >= 38.0, p8
     assert abs(psnr(outs[True], tgt) - psnr(want, tgt)) <= 0.1
+
+
+def test_few_levels_256x448_forward_bf16_and_fp8_vs_oracle():
+    """BASELINE configs[4] at its own frame size and width (the two halves had only been tested apart): the C = 144
+    few_levels network on a 3-frame clip of 256 x 448 -- the recurrent chains' launches see M = 2 * 256 * 448 = 229 376 pixels, seven tiles of
+    the weight-streaming / fp8 kernel per CU -- in bf16 and with fp8 chains, against the fp32 oracle (about a minute of host time).  Stated
+    tolerances: bf16 PSNR >= 40 dB, fp8 chains >= 38 dB, |PSNR(hip, target) - PSNR(oracle, target)| <= 0.05 / 0.1 dB."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from oracle import vmg_oracle as O
+    from tests.util import build_product, psnr
+    from vmg_amd import functional as FH
+    cfg = C.cfg_reds_few(T=3)
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_reds_few_cfg1.npz"))
+    chunk_of, window_of = R.vmg_chunk_lookup(cfg)
+    sd = R.recipe_state_dict(shapes, 0, chunk_of, window_of)
+    x = R.synthetic_clip(1, 3, 256, 448, 78)
+    tgt = R.synthetic_target(x)
+    outs = {}
+    for fp8 in (False, True):
+        m = build_product(cfg, torch.bfloat16)
+        m.load_state_dict(sd)
+        m.eval()
+        m.fp8_chains = fp8
+        n0 = FH.FP8_STATS["chains"]
+        with torch.no_grad():
+            outs[fp8] = m(x.cuda()).float().cpu()
+        assert (FH.FP8_STATS["chains"] - n0) == (2 * 3 if fp8 else 0)
+        del m
+        torch.cuda.empty_cache()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        want = O.vmg_forward({k: v.clone() for k, v in sd.items()}, cfg, x)
+    p16, p8 = psnr(outs[False], want), psnr(outs[True], want)
+    d16, d8 = abs(psnr(outs[False], tgt) - psnr(want, tgt)), abs(psnr(outs[True], tgt) - psnr(want, tgt))
+    print(f"256x448, C = 144, T = 3: PSNR vs the fp32 oracle: bf16 {p16:.2f} dB, fp8 chains {p8:.2f} dB; PSNR-vs-target difference {d16:.4f} / {d8:.4f} dB")
+    assert p16 >= 40.0 and d16 <= 0.05, (p16, d16)
+    assert p8 >= 38.0 and d8 <= 0.1, (p8, d8)

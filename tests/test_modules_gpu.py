@@ -193,6 +193,44 @@ def test_swin_decoder_layer_fwd_bwd(name, dtype):
         assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_one_window_map_matches_oracle(dtype):
+    """A feature map of exactly one spatial window (8 x 8) and exactly one temporal window (D = wt): models/swin_3d.py:88-101 then sets the
+    window to the map and ZEROES the shift of the odd block -- the case of get_window_size that the reference can run (smaller maps fail in
+    it, tests/test_host_logic.py::test_small_feature_maps_raise_like_the_reference).  Forward and all gradients vs the oracle."""
+    from oracle import cases as C, recipe as R, vmg_oracle as O
+    from vmg_amd.model import DecoderLayer
+    case = C.CASES["swin_w2_t5"]
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "swin_w2_t5.npz"))
+    sd = C.case_state_dict(case, shapes)
+    ws, heads = (2, 8, 8), 4
+    x = R.seeded((2, 2, 8, 8, 32), 97)
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()
+    osd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.swin_decoder_layer(osd, "", xo, heads, ws)
+    go = R.seeded(tuple(want.shape), 98)
+    if dtype == torch.bfloat16:
+        go = go.to(dtype).float()
+    leaves = [k for k in sorted(osd) if osd[k].dtype.is_floating_point]
+    wg = torch.autograd.grad(want, [xo] + [osd[k] for k in leaves], go, allow_unused=True)
+    m = DecoderLayer(32, 2, heads, list(ws), 2, True).cuda()
+    m.load_state_dict(sd, strict=True)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    got = m(xd)
+    got.backward(go.cuda().to(dtype))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert float((got.float().cpu() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((xd.grad.float().cpu() - wg[0]).abs().max()) <= tol * max(1.0, float(wg[0].abs().max()))
+    params = dict(m.named_parameters())
+    for k, gw in zip(leaves, wg[1:]):
+        if gw is None:
+            continue
+        err = float((params[k].grad.cpu() - gw).abs().max())
+        assert err <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, float(gw.abs().max())), f"{k}: {err}"
+
+
 def _fixture(name):
     from oracle import cases as C
     case = C.CASES[name]
