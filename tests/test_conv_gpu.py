@@ -416,6 +416,12 @@ def test_conv_ws_bias_relu(shape):
     pw = K.pack_conv_weight_ws(w.cuda(), cout_tiles=tiles)
     got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_RELU, deep=3)
     _cmp(got, want, dtype, f"conv ws {shape}")
+    if Co % 48 == 0:
+        # round 4: the 48-channel-block instance (three workgroups per tile, two workgroups per CU) -- the same arithmetic in the same order
+        # per output element (same K order, fp32 accumulate), so the SAME BITS as the 144-channel-block instance
+        pw3 = K.pack_conv_weight_ws(w.cuda(), cout_tiles=3)
+        got3, _ = K.conv_forward([x.cuda().to(dtype)], pw3, b.cuda(), N, H, W, act=hip.ACT_RELU, deep=3)
+        assert torch.equal(got3, got), f"conv ws, 48-channel blocks {shape}"
 
 
 def test_conv_ws_concat_residual_gelu_pre_dgrad():
