@@ -377,7 +377,7 @@ def main():
             avg_s = raw_us * 1e-6
             ach = k1_flops / avg_s / 1e12
             traffic = None  # HBM bytes per launch of this kernel from the PMC passes recorded under profiles/ (not measurable live)
-            pmc_file = "r03_g_q8_pmc.json" if args.fp8 else "r03_g_k1_pmc.json"
+            pmc_file = "r03_g_q8_pmc.json" if args.fp8 else "r04_a_k1_pmc.json"
             if wl["ch"] == 144 and k1_pixels == 32768:
                 try:
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:

@@ -956,12 +956,7 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3b_kernel(const Wgrad2K 
 #ifdef VMG_DIAG
       if (!(a.dbg & 4))
 #endif
-      bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);
-      if (jj == 6) {  // (a select, not a branch: wave-uniform condition, four v_cndmask)
-        const bf16x8 rd = bfg[6];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bfg[6][e] = bias_col ? one : rd[e];
-      }
+      if (jj < 6 || !bias_col) bfg[jj] = tr_read(src + b_off[jj], W2_XC * 2);  // (q = 3: column 6 stays the ones operand; a wave-uniform skip of two reads)
     }
 #ifdef VMG_DIAG
     if (!(a.dbg & 4))
