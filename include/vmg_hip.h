@@ -378,12 +378,20 @@ int vmg_morph_tokens_scatter(int dtype, int axis, int chunk, const void* tok, vo
  * zeros are padded before the Linears; pass null for bias-free Linears), the cyclic roll by (sd, sh, sw) of shifted blocks, the -100 region mask
  * and the relative-position bias gather (table (n_rel, heads) for the (wt, 8, 8) window) are index arithmetic inside the kernel.  Every time
  * slice's queries attend to the tokens of the other slices of their window.  out (B, D, H, W, C); lse (windows, heads, wt*64) fp32 is kept for the
- * backward, which writes dq, dkv and accumulates (+=) dtable and, for gradient reaching the biases through padded positions, dbq / dbkv (may be null). */
+ * backward, which writes dq, dkv and accumulates (+=) dtable and, for gradient reaching the biases through padded positions, dbq / dbkv (may be null).
+ * ws (may be null): vmg_win3d_attn_bwd_ws_bytes(...) bytes -- every (window, head) workgroup's table gradient goes there with plain stores and a
+ * second launch adds the windows in a fixed order (bit-reproducible); without it the workgroups add into dtable with float atomics (1 575 per
+ * workgroup onto the same addresses: the launch is then bound by them). */
 int vmg_win3d_attn_fwd(int dtype, const void* q, const void* kv, const float* bq, const float* bkv, const float* table, void* out, float* lse,
                        int B, int D, int H, int W, int C, int heads, int wt, int sd, int sh, int sw, void* stream);
+int64_t vmg_win3d_attn_bwd_ws_bytes(int B, int D, int H, int W, int heads, int wt);
 int vmg_win3d_attn_bwd(int dtype, const void* q, const void* kv, const float* bq, const float* bkv, const float* table, const void* out,
-                       const float* lse, const void* d_out, void* dq, void* dkv, float* dtable, float* dbq, float* dbkv, int B, int D, int H, int W,
+                       const float* lse, const void* d_out, void* dq, void* dkv, float* dtable, float* dbq, float* dbkv, void* ws, int B, int D, int H, int W,
                        int C, int heads, int wt, int sd, int sh, int sw, void* stream);
+/* Tuning knob (tests, A/B): 1 (default) the MFMA kernels for bf16 tensors with an even head dimension <= 32 (QK^T, PV and their gradients on
+ * v_mfma_f32_16x16x32_bf16), 0 the VALU kernel (one thread per token) for everything.  fp32 tensors always take the VALU kernel.  Returns the
+ * previous value; any other argument only queries. */
+int vmg_win3d_variant(int variant);
 
 /* ---- multi-scale skip (MDSC; reference: models/vmg.py:388-400, 519, 525): adaptive_max_pool2d to (H/f, W/f) as non-overlapping f x f
  * windows (f must divide H and W; f = 4 in the model).  idx (N, H/f, W/f, C) bytes: position of the winner inside its window.

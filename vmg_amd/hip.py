@@ -102,10 +102,12 @@ SIGNATURES = {
     "vmg_win3d_attn_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_void_p]),
     "vmg_win3d_attn_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_win3d_attn_bwd_ws_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vmg_conv_wgrad3_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_conv_wgrad3_variant": (c_int, [c_int]),
+    "vmg_win3d_variant": (c_int, [c_int]),
     "vmg_linear_wgrad2_multi": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_replay_build": (c_void_p, [c_void_p, c_void_p, c_void_p]),

@@ -548,8 +548,10 @@ def win3d_attn_backward(q, kv, bq, bkv, table, out, lse, dout, heads: int, wt: i
         dbq = torch.zeros(C, dtype=torch.float32, device=q.device) if bq is not None else None
         dbkv = torch.zeros(2 * C, dtype=torch.float32, device=q.device) if bkv is not None else None
     pz = lambda t: t.data_ptr() if t is not None else None
+    # per-workgroup table gradients + an ordered reduce launch instead of float atomics from every window onto the same table (kernel doc)
+    ws = torch.empty(int(hip.lib().vmg_win3d_attn_bwd_ws_bytes(B, D, H, W, heads, wt)), dtype=torch.uint8, device=q.device)
     hip.check(hip.lib().vmg_win3d_attn_bwd(hip.dtype_code(q.dtype), q.data_ptr(), kv.data_ptr(), pz(bq), pz(bkv), table.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                           dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dtable.data_ptr(), pz(dbq), pz(dbkv), B, D, H, W, C, heads, wt,
+                                           dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dtable.data_ptr(), pz(dbq), pz(dbkv), ws.data_ptr(), B, D, H, W, C, heads, wt,
                                            shift[0], shift[1], shift[2], hip.stream_ptr()), "vmg_win3d_attn_bwd")
     return dq, dkv, dtable, dbq, dbkv
 
