@@ -211,3 +211,57 @@ def test_forward_is_bit_reproducible_and_gradients_repeat(dtype):
             worst = (e, k)
     print(f"run-to-run gradient difference ({dtype}): relative L2 {worst[0]:.2e} at {worst[1]}")
     assert worst[0] <= (4e-3 if dtype == torch.bfloat16 else 1e-5), worst
+
+
+def _poison_allocator():
+    """Fill the caching allocator's free blocks with NaN bit patterns (blocks of many sizes, then freed): a kernel that reads memory nobody
+    wrote -- a torch.empty output it assumes zeroed, a workspace tail, padded channels -- and lets it reach a result then produces a NaN or a
+    different bit pattern."""
+    bufs = []
+    for k in range(9, 27):
+        for _ in range(max(1, min(32, (256 << 20) // (4 << k)))):
+            bufs.append(torch.full((1 << k,), float("nan"), device="cuda"))
+    torch.cuda.synchronize()
+    del bufs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_results_do_not_depend_on_what_freed_memory_held(dtype):
+    """Round 4 found a kernel pair that relied on a zero-fill a captured graph did not replay (the flow up-sampling backward).  The general form
+    of that bug class: run the same forward + backward twice, the second time with every free block of the allocator poisoned with NaN.  The
+    forward output must be the same bits, every gradient finite and equal up to the run-to-run bound of the float-atomic reductions."""
+    from oracle import cases as C
+    from oracle import recipe as R
+    from tests.util import build_product
+    from vmg_amd import functional as FH
+    case = C.CASES["vmg_tiny_swin"]  # (the tiny few-levels model WITH the window attention: every kernel family of the path)
+    shapes, _ = C.load_fixture(os.path.join(GOLD, "vmg_tiny_swin.npz"))
+    sd = C.case_state_dict(case, shapes)
+    x = R.synthetic_clip(1, 4, 64, 64, 48).cuda()
+    tgt = R.synthetic_target(x.cpu()).cuda()
+    runs = []
+    FH.set_wgrad_mode("deferred")
+    try:
+        for poisoned in (False, True):
+            m = build_product(case["cfg"], dtype)
+            m.load_state_dict(sd)
+            m.train()
+            if poisoned:
+                _poison_allocator()
+            out = m(x)
+            loss = (out.float() - tgt).square().mean()
+            loss.backward()
+            FH.flush_deferred_wgrads()
+            torch.cuda.synchronize()
+            runs.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+            del m, out, loss
+    finally:
+        FH.set_wgrad_mode("autograd")
+    assert torch.isfinite(runs[1][0]).all()
+    assert torch.equal(runs[0][0], runs[1][0]), "the forward output changed when freed memory held NaNs"
+    nmax = max(float(g.norm()) for g in runs[0][1].values())
+    for k, a in runs[0][1].items():
+        b = runs[1][1][k]
+        assert torch.isfinite(b).all(), f"{k}: non-finite gradient with a poisoned allocator"
+        e = float((a.double() - b.double()).norm()) / max(float(a.norm()), 1e-3 * nmax)
+        assert e <= (4e-3 if dtype == torch.bfloat16 else 1e-5), (k, e)

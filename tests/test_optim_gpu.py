@@ -397,3 +397,36 @@ def test_accumulation_clips_every_micro_step_like_the_reference():
     gmax = max(float(v.abs().max()) for v in want.values())
     for n in got:
         assert float((got[n] - want[n]).abs().max()) <= 5e-3 * max(float(want[n].abs().max()), 1e-3 * gmax), n
+
+
+def test_replayed_steps_survive_allocator_churn():
+    """A captured step replayed 10 times while the caching allocator hands the same free blocks to NaN-filled tensors between replays: SPyNet, whose
+    learning rate is 0, must stay bit-identical (0 x NaN is NaN: any non-finite gradient shows), the loss finite, and no tensor allocated between
+    replays may be overwritten by the graph (a node writing through the address of memory that was freed after the capture).  This is the scenario in
+    which round 3's `hipMemsetAsync` node and the freed pack-plan tables failed."""
+    import os
+    from oracle import cases as C
+    from tests.util import build_product
+    from vmg_amd.train import TrainStep
+    from vmg_amd.data import synthetic_clip, synthetic_target
+    cfg = C.cfg_tiny_few(3, is_train=False)
+    shapes, _ = C.load_fixture(os.path.join(os.path.dirname(__file__), "golden", "vmg_tiny_few.npz"))
+    sd = C.case_state_dict(C.CASES["vmg_tiny_few"], shapes)
+    x = synthetic_clip(1, 3, 64, 64, seed=76, device="cuda")
+    y = synthetic_target(x)
+    m = build_product(cfg, torch.float32)
+    m.load_state_dict(sd)
+    m.train()
+    ts = TrainStep(m, lr=2e-4, spynet_lr=0.0)
+    spy0 = torch.cat([p.detach().reshape(-1).clone() for p in m.spynet.parameters()])
+    ts.capture(x, y, warmup=2)
+    canaries = []
+    for n in range(10):
+        loss = ts(x, y)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss), n
+        spy = torch.cat([p.detach().reshape(-1) for p in m.spynet.parameters()])
+        assert torch.equal(spy, spy0), f"replay {n}: SPyNet (lr 0) changed by {float((spy - spy0).abs().max())}"
+        for c in canaries:
+            assert bool(torch.isnan(c).all()), f"replay {n}: the graph wrote into memory allocated after the capture"
+        canaries = [torch.full((sz,), float("nan"), device="cuda") for sz in (256, 4096, 65536, 1 << 20) for _ in range(6)]
