@@ -213,3 +213,52 @@ def test_small_feature_maps_raise_like_the_reference():
             assert tuple(ws) != (2, 8, 8)
             with pytest.raises(HipError):
                 blk(torch.zeros(1, 4, h, w, 32))  # (raised before any kernel call: no GPU needed)
+
+
+def test_kernels_with_hand_counted_waits_have_no_scratch():
+    """ADVICE round 3 (conv_igemm.hip, conv_wstat_kernel): kernels that count their own vector-memory operations (`s_waitcnt vmcnt(N)` in front of a
+    barrier, with LDS-DMA copies still in flight) are only correct while hipcc adds none of its own -- a register spill is a scratch store / load
+    that the count does not know about, and a spilled reload is followed by `vmcnt(0)`.  The built library's kernel metadata is read back
+    (llvm-objcopy / clang-offload-bundler / llvm-readelf from the ROCm install) and every such kernel must report a private segment of 0 bytes.
+    (Round 4's experiments hit exactly this: two variants of the weight-gradient kernel compiled to 3 KB of scratch per lane and ran 25x slower.)"""
+    import subprocess
+    import tempfile
+    from vmg_amd import hip
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    counted = ("conv_ws_kernel", "conv_wstat_kernel", "conv_wgrad3_kernel", "conv_wgrad3b_kernel", "linear_wgrad2_kernel", "convq8_kernel")
+    seen = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([tools[0], "--dump-section", f".hip_fatbin={fat}", hip.LIB_PATH, os.path.join(td, "copy.so")], check=True)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m for m in range(len(blob)) if blob.startswith(magic, m)] if len(blob) < (1 << 20) else []
+        if not starts:  # (large section: search with find)
+            pos = blob.find(magic)
+            while pos >= 0:
+                starts.append(pos)
+                pos = blob.find(magic, pos + 1)
+        assert starts, "no offload bundle in .hip_fatbin"
+        for i, st in enumerate(starts):
+            end = starts[i + 1] if i + 1 < len(starts) else len(blob)
+            part, co = os.path.join(td, f"b{i}.bin"), os.path.join(td, f"b{i}.co")
+            open(part, "wb").write(blob[st:end])
+            r = subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"],
+                               capture_output=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True).stdout
+            name = None
+            for line in notes.splitlines():
+                line = line.strip()
+                if line.startswith(".name:"):
+                    name = line.split(":", 1)[1].strip()
+                elif line.startswith(".private_segment_fixed_size:") and name is not None:
+                    seen[name] = int(line.split(":", 1)[1])
+    hits = {k: v for k, v in seen.items() if any(c in k for c in counted)}
+    assert len(hits) >= 8, f"kernel metadata not found (parsed {len(seen)} kernels)"
+    bad = {k: v for k, v in hits.items() if v != 0}
+    assert not bad, f"kernels with hand-counted waits that use scratch: {bad}"

@@ -269,3 +269,29 @@ def test_morph_linear_general_path_equals_the_torch_spelling(dtype, geom):
     for i in (1, 2, 3):
         a, bb = res[0][i].float(), res[1][i].float()
         assert float((a - bb).abs().max()) <= 1e-5 * max(1.0, float(bb.abs().max())) if dtype == torch.float32 else float((a - bb).abs().max()) <= 2e-2 * float(bb.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_gate_residual_one_pass_equals_gate_then_residual(dtype, drop):
+    """functional.gate_residual (round 4): res + DropPath((x + y) tanh(y)) * s in one pass each way -- the same bits as tanh_gate followed by
+    residual_drop_path (models/function.py:801-802, 1212-1214), forward and all three gradients, with and without dropped samples."""
+    from oracle import recipe as R
+    from vmg_amd import functional as FH
+    shape = (3, 2, 8, 8, 144)
+    res = []
+    for fused in (False, True):
+        x = R.seeded(shape, 1400).to(dtype).cuda().requires_grad_(True)
+        y = R.seeded(shape, 1401).to(dtype).cuda().requires_grad_(True)
+        r = R.seeded(shape, 1402).to(dtype).cuda().requires_grad_(True)
+        torch.manual_seed(5)  # (the per-call DropPath mask: same draw in both runs)
+        FH.DROP.begin(x.device, False)
+        if fused:
+            out = FH.gate_residual(x, y, r, drop, True, 0.5)
+        else:
+            out = FH.residual_drop_path(r, FH.tanh_gate(x, y), drop, True, 0.5)
+        g = R.seeded(shape, 1403).to(dtype).cuda()
+        out.backward(g)
+        res.append((out.detach(), x.grad, y.grad, r.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

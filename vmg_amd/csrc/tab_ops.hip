@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void group_reduce3_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6, OP_SCALE = 7 };
+enum { OP_CA_FWD = 0, OP_CA_BWD = 1, OP_MIX_FWD = 2, OP_MIX_BWD = 3, OP_GATE_FWD = 4, OP_GATE_BWD = 5, OP_AFFINE2 = 6, OP_SCALE = 7, OP_GATE_RES_FWD = 8, OP_GATE_RES_BWD = 9 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict__ p0, const T* __restrict__ p1, const T* __restrict__ p2,
@@ -224,6 +224,29 @@ __global__ __launch_bounds__(256) void tab_ew_kernel(int op, const T* __restrict
         r0.v[e] = from_f32<T>(s > 0.5f ? fmaxf(t, 0.f) : t);
       }
       *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else if (op == OP_GATE_RES_FWD) {  // res + (x + y) * tanh(y) * g: p0 = x, p1 = y, p2 = res, coef (G, C) -- the mixer's gate and the TAB residual
+      const V16<T> y = *reinterpret_cast<const V16<T>*>(p1 + off);                       // (with its DropPath coefficient) in ONE pass
+      const V16<T> r = *reinterpret_cast<const V16<T>*>(p2 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float yv = to_f32(y.v[e]);
+        // (the gate is rounded to T first, as the two-pass form stored it: same bits)
+        const float gate = to_f32(from_f32<T>((to_f32(a.v[e]) + yv) * tanhf(yv)));
+        r0.v[e] = from_f32<T>((gate * coef[gc + e] + to_f32(r.v[e])) * s);
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+    } else if (op == OP_GATE_RES_BWD) {  // p0 = dout, p1 = x, p2 = y: d = dout * g (rounded to T like the two-pass form), dx = d*t, dy = d*(t + (x+y)(1-t^2))
+      const V16<T> x = *reinterpret_cast<const V16<T>*>(p1 + off);
+      const V16<T> y = *reinterpret_cast<const V16<T>*>(p2 + off);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float d = to_f32(from_f32<T>(to_f32(a.v[e]) * coef[gc + e] * s)), xv = to_f32(x.v[e]), yv = to_f32(y.v[e]);
+        const float t = tanhf(yv);
+        r0.v[e] = from_f32<T>(d * t);
+        r1.v[e] = from_f32<T>(d * (t + (xv + yv) * (1.f - t * t)));
+      }
+      *reinterpret_cast<V16<T>*>(o0 + off) = r0;
+      *reinterpret_cast<V16<T>*>(o1 + off) = r1;
     } else if (op == OP_GATE_FWD) {  // (x + y) * tanh(y): p0 = x, p1 = y
       const V16<T> y = *reinterpret_cast<const V16<T>*>(p1 + off);
 #pragma unroll
@@ -539,7 +562,7 @@ extern "C" int vmg_group_reduce3(int dtype, const void* a, const void* b0, const
 extern "C" int vmg_tab_elementwise(int dtype, int op, const void* p0, const void* p1, const void* p2, const float* coef, const float* add,
                                    float s, void* o0, void* o1, void* o2, int64_t rows, int64_t R, int C, void* stream) {
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "tab_elementwise: bad dtype");
-  VMG_CHECK(op >= 0 && op <= 7 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
+  VMG_CHECK(op >= 0 && op <= 9 && p0 && o0 && rows > 0 && R > 0 && C > 0, "tab_elementwise: bad arguments");
   const int vn = dtype == VMG_BF16 ? 8 : 4;
   VMG_CHECK(C % vn == 0, "tab_elementwise: C must be a multiple of %d", vn);
   const long long total = rows * (C / vn);

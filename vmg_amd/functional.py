@@ -1363,6 +1363,48 @@ def tanh_gate(x, y):
     return _TanhGate.apply(x, y)
 
 
+class _GateResidual(_Fn):
+    """res + DropPath((x + y) * tanh(y)) * s: the mixer's symmetric gate (models/function.py:801-802) and the TAB residual around the mixer
+    (function.py:1212-1214) in ONE pass each way -- the gated tensor is neither written nor read back (round 3 ran tanh_gate, then
+    residual_drop_path: two passes forward, two backward, per TAB).  Same bits as the two-pass form: the gate is rounded to the tensor dtype
+    before the residual coefficient is applied, as when it was stored."""
+
+    @staticmethod
+    def forward(ctx, x, y, res, g):
+        x, y, res = x.contiguous(), y.contiguous(), res.contiguous()
+        ctx.save_for_backward(x, y, g)
+        return K.tab_elementwise(K.OP_GATE_RES_FWD, x, y, res, coef=g, s=1.0, G=g.shape[0])
+
+    @staticmethod
+    def backward(ctx, d):
+        x, y, g = ctx.saved_tensors
+        d = d.contiguous()
+        dx, dy = K.tab_elementwise(K.OP_GATE_RES_BWD, d, x, y, coef=g, s=1.0, G=g.shape[0], nout=2)
+        return dx, dy, d, None
+
+
+_ONES = {}
+
+
+def gate_residual(x: torch.Tensor, y: torch.Tensor, res: torch.Tensor, p: float, training: bool, scale: float = 1.0) -> torch.Tensor:
+    """res + DropPath_p((x + y) * tanh(y)) * scale (timm DropPath semantics, see residual_drop_path) as one kernel."""
+    B, C = y.shape[0], y.shape[-1]
+    if p > 0.0 and training:
+        keep = 1.0 - p
+        g, _ = DROP.take(B, C, keep, scale, y.dtype)
+        if g is None:
+            mask = torch.empty(B, 1, dtype=torch.float32, device=y.device).bernoulli_(keep)
+            if keep > 0.0:
+                mask.div_(keep)
+            g = (mask * scale).expand(B, C).contiguous()
+    else:
+        key = (B, C, float(scale), str(y.device))
+        g = _ONES.get(key)
+        if g is None:
+            g = _ONES[key] = torch.full((B, C), float(scale), dtype=torch.float32, device=y.device)
+    return _GateResidual.apply(x, y, res, g)
+
+
 class _MaxPool(_Fn):
     @staticmethod
     def forward(ctx, x, f):

@@ -853,7 +853,7 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
     return dq, dk, dv, drpe
 
 
-OP_CA_FWD, OP_CA_BWD, OP_MIX_FWD, OP_MIX_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_AFFINE2, OP_SCALE = range(8)
+OP_CA_FWD, OP_CA_BWD, OP_MIX_FWD, OP_MIX_BWD, OP_GATE_FWD, OP_GATE_BWD, OP_AFFINE2, OP_SCALE, OP_GATE_RES_FWD, OP_GATE_RES_BWD = range(10)
 
 
 def group_reduce(a: torch.Tensor, G: int, b: Optional[torch.Tensor] = None, c3: Optional[torch.Tensor] = None, mode: int = 0,

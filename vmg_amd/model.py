@@ -241,8 +241,10 @@ class Enhanced_MorphFCs_decay(nn.Module):
 
     N_HANDLES = 5  # consumers of the mixer's input: H branch, W branch, channel branch (RCAB: conv + residual), tanh gate
 
-    def forward(self, x):
-        """x: the normalised features (B,T,H,W,C), or a list of N_HANDLES autograd handles of them (functional.layer_norm_fan)."""
+    def forward(self, x, residual=None):
+        """x: the normalised features (B,T,H,W,C), or a list of N_HANDLES autograd handles of them (functional.layer_norm_fan).
+        residual = (res, drop_prob, training, scale): return res + DropPath(mixer(x)) * scale instead of mixer(x) -- the TAB residual taken
+        inside the gate's pass (functional.gate_residual)."""
         xs = list(x) if isinstance(x, (list, tuple)) else [x] * self.N_HANDLES
         x = xs[0]
         B, T, H, W, C = x.shape
@@ -262,6 +264,8 @@ class Enhanced_MorphFCs_decay(nn.Module):
         rw = self.reweight
         y = FH.reweight_mix(h, w, c, rw.fc1.weight, rw.fc1.bias, rw.fc2.weight, rw.fc2.bias)
         y = lin(self.proj, y)
+        if residual is not None:
+            return FH.gate_residual(xs[4], y, *residual)
         return FH.tanh_gate(xs[4], y)
 
 
@@ -308,8 +312,7 @@ class TAB(nn.Module):
             n2, xs = FH.layer_norm_fan(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, Enhanced_MorphFCs_decay.N_HANDLES)
         else:
             n2, xs = FH.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        y = self.spatial_mixing(n2)
-        x = FH.residual_drop_path(xs, y, self.drop_prob, self.training, s)  # one pass: mask, scale and add
+        x = self.spatial_mixing(n2, residual=(xs, self.drop_prob, self.training, s))  # gate, DropPath mask, scale and residual add: one pass
         n3, xs = FH.layer_norm_skip(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         if isinstance(self.channel_mixing, Mlp_cnn) and not dp and s == 1.0:
             return self.channel_mixing(n3, res=xs)  # residual fused in the Linear epilogue
