@@ -227,6 +227,7 @@ def main():
                     "MFMA; SURVEY 8f-4 / BASELINE configs[4]) in the forward pass; the roofline object then prices the fp8 kernel against the 5 PFLOP/s fp8 peak")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--wgrad3-variant", type=int, default=-1, help="vmg_conv_wgrad3_variant (0: round 2's kernel, 1: conv_wgrad3b_kernel; -1 keeps the default): A/B on one box")
+    ap.add_argument("--grouped-dense", type=int, default=-1, help="functional.GROUPED_DENSE (0: grouped convolutions as G launches, 1: one launch on the dense block-diagonal pack; -1 keeps the default): A/B on one box")
     ap.add_argument("--win3d-variant", type=int, default=-1, help="vmg_win3d_variant (0: VALU window-attention kernel, 1: MFMA; -1 keeps the default): A/B on one box")
     ap.add_argument("--spynet-edge-fp32", type=int, default=-1, help="override SPyNet.edge_fp32 (0 / 1; -1 keeps the model's default): A/B of its cost")
     ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other BASELINE configurations that the default "
@@ -331,6 +332,9 @@ def main():
         lib.vmg_conv_wgrad3_variant(args.wgrad3_variant)
     if args.win3d_variant >= 0:
         lib.vmg_win3d_variant(args.win3d_variant)
+    if args.grouped_dense >= 0:
+        from vmg_amd import functional as FH_
+        FH_.GROUPED_DENSE = bool(args.grouped_dense)
     if use_graph:
         # (the live HIP-event sampler cannot time kernels inside a replayed graph on this ROCm: event records captured with the step -- plain or
         #  hipEventRecordExternal -- return no timing or fail the capture; a graph run therefore reports no roofline object)

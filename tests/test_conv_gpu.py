@@ -734,3 +734,40 @@ def test_conv_wgrad3_kernel_variants_give_the_same_bits(shape):
     assert prev == 1
     assert torch.isfinite(outs[1][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("geom", [(2, 16, 16, 112, 672, 4), (7, 64, 64, 112, 672, 4), (7, 32, 32, 224, 1344, 4), (7, 8, 8, 448, 2688, 4), (1, 9, 11, 64, 128, 2)])
+def test_grouped_conv_dense_route_matches_grouped_launches(geom):
+    """Round 4: a grouped 3x3 convolution (Mlp_cnn.fc1 of the full configuration, models/function.py:50-79, n_groups = 4) as ONE launch on the
+    dense block-diagonal pack the pack kernels build from the grouped parameter, forward and data gradient, against the G launches of round 3
+    (functional.GROUPED_DENSE off).  The extra products are exact zeros; what differs is the fp32 summation order inside a launch: output and
+    input gradient within 1e-2 of their scale (bf16 outputs), the weight / bias gradients (same grouped kernel either way, fed the two routes'
+    bf16 pre-activation gradients) within 2e-2."""
+    hip, K, O, R = _setup()
+    from vmg_amd import functional as FH
+    N, H, W, C, Oc, G = geom
+    dt = torch.bfloat16
+    res = []
+    for dense in (False, True):
+        FH.clear_pack_cache()
+        FH.GROUPED_DENSE = dense
+        try:
+            x = R.seeded((N, H, W, C), 1500).to(dt).cuda().requires_grad_(True)
+            w = torch.nn.Parameter(R.seeded((Oc, C // G, 3, 3), 1501, (C // G * 9) ** -0.5).cuda())
+            b = torch.nn.Parameter(R.seeded((Oc,), 1502, 0.1).cuda())
+            y = FH.grouped_conv2d(x, w, b, G, N, H, W, ks=3, act=hip.ACT_GELU)
+            g = R.seeded((N, H, W, Oc), 1503).to(dt).cuda()
+            y.backward(g)
+            res.append((y.detach().float(), x.grad.float(), w.grad.float(), b.grad.float()))
+        finally:
+            FH.GROUPED_DENSE = True
+    for name, tol, a, bb in zip(("out", "dx", "dW", "db"), (1e-2, 1e-2, 2e-2, 2e-2), res[0], res[1]):
+        assert torch.isfinite(bb).all(), name
+        err = float((a - bb).abs().max())
+        assert err <= tol * max(float(a.abs().max()), 1e-6), f"{name}: {err:.3e} vs scale {float(a.abs().max()):.3e} ({geom})"
+    # and against torch's grouped convolution in fp32 on the same bf16-rounded operands
+    xr = R.seeded((N, H, W, C), 1500).to(dt).float()
+    wr = R.seeded((Oc, C // G, 3, 3), 1501, (C // G * 9) ** -0.5).to(dt).float()
+    br = R.seeded((Oc,), 1502, 0.1)
+    want = F.gelu(F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=G)).permute(0, 2, 3, 1)
+    assert float((res[1][0].cpu() - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))

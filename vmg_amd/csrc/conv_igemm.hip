@@ -1591,8 +1591,27 @@ struct PackK {
   const float* w;
   char* out;
   int O, I, ks, o0, on, nsrc, transpose_flip, cob, ncb, nstages, ss_elems;  // ss_elems = stage stride in elements
+  int groups;  // > 1: w is the (O, I, ks, ks) weight of a GROUPED convolution (I = channels per group); the pack is the dense block-diagonal operator
   short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_st0[MAX_ISRC], src_nst[MAX_ISRC];
 };
+
+// one weight value of the (possibly grouped) operator: forward packs ask (output channel oc, K-side input channel kc), data-gradient packs
+// (output = input channel oc, K-side output channel kc, mirrored tap).  groups > 1: the dense block-diagonal image of the grouped convolution
+// -- zero wherever the two channels belong to different groups -- so that ALL groups run as ONE convolution launch (round 4: the full
+// configuration's Mlp_cnn.fc1, n_groups = 4, was four launches per call and direction on 28 -> 168 .. 112 -> 672 channel slices).
+__device__ __forceinline__ float pack_weight_value(const PackK& p, int oc, int kc, int tap, int KK) {
+  if (p.groups <= 1) {
+    if (!p.transpose_flip) return p.w[((long long)oc * p.I + kc) * KK + tap];
+    return p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
+  }
+  const int og = p.O / p.groups;
+  if (!p.transpose_flip) {
+    const int kl = kc - (oc / og) * p.I;
+    return (kl >= 0 && kl < p.I) ? p.w[((long long)oc * p.I + kl) * KK + tap] : 0.f;
+  }
+  const int g = oc / p.I;  // oc: dense input channel
+  return (kc / og == g) ? p.w[((long long)kc * p.I + (oc - g * p.I)) * KK + (KK - 1 - tap)] : 0.f;
+}
 
 // one packed element of [cout block][stage][stage image]; a stage image is [k-step j][chunk g][co][8] followed by zero padding up to
 // the 4-KiB-aligned stage stride
@@ -1622,8 +1641,7 @@ __device__ __forceinline__ void pack_std_elem(const PackK& p, long long i) {
     if (q < CH && col < p.on) {
       const int kc = p.src_off[s] + q * 8 + e;  // K-side channel
       const int oc = p.o0 + col;                // output-side channel
-      if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * KK + tap];
-      else v = p.w[((long long)kc * p.I + oc) * KK + (KK - 1 - tap)];
+      v = pack_weight_value(p, oc, kc, tap, KK);
     }
   }
   reinterpret_cast<T*>(p.out)[i] = from_f32<T>(v);
@@ -1654,8 +1672,7 @@ __device__ __forceinline__ void pack_ws_elem(const PackK& p, long long i) {
   if (tap >= 0 && col < p.on) {
     const int kc = p.src_off[s] + chunk * 8 + e;
     const int oc = p.o0 + col;
-    if (!p.transpose_flip) v = p.w[((long long)oc * p.I + kc) * 9 + tap];
-    else v = p.w[((long long)kc * p.I + oc) * 9 + (8 - tap)];
+    v = pack_weight_value(p, oc, kc, tap, 9);
   }
   reinterpret_cast<bf16*>(p.out)[i] = (bf16)v;
 }
@@ -1942,7 +1959,7 @@ static int fill_pack_std(PackK& p, long long& total, int dtype, const float* w, 
   VMG_CHECK(ks == 1 || ks == 3 || ks == 7, "conv_pack: ks must be 1, 3 or 7");
   VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "conv_pack: bad dtype");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "conv_pack: nsrc must be 1..4");
-  VMG_CHECK(!transpose_flip || nsrc == 1, "conv_pack: data-gradient packing takes one K slice");
+  VMG_CHECK(!(transpose_flip & 1) || nsrc == 1, "conv_pack: data-gradient packing takes one K slice");
   VMG_CHECK(cout_tiles >= 1 && cout_tiles <= 9, "conv_pack: cout_tiles must be 1..9");
   memset(&p, 0, sizeof(p));
   const int n = expand_sources(nsrc, src_off, src_ch, p.src_off, p.src_ch, nullptr);
@@ -1954,11 +1971,15 @@ static int fill_pack_std(PackK& p, long long& total, int dtype, const float* w, 
     st += p.src_nst[s];
   }
   // bounds of the slices against the weight tensor
-  const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
+  const int groups = (transpose_flip >> 8) > 1 ? (transpose_flip >> 8) : 1;  // (bits 8.. of the flag word: see vmg_hip.h)
+  transpose_flip &= 1;
+  VMG_CHECK(groups == 1 || (O % groups == 0), "conv_pack: output channels must divide into the groups");
+  const int Id = I * groups;  // dense input channels
+  const int kdim = transpose_flip ? O : Id, odim = transpose_flip ? Id : O;
   for (int s = 0; s < n; ++s) VMG_CHECK(p.src_off[s] >= 0 && p.src_off[s] + p.src_ch[s] <= kdim, "conv_pack: K slice out of range");
   VMG_CHECK(o0 >= 0 && o0 + on <= odim, "conv_pack: output slice out of range");
   p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = ks; p.o0 = o0; p.on = on; p.nsrc = n;
-  p.transpose_flip = transpose_flip; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.nstages = st;
+  p.transpose_flip = transpose_flip; p.groups = groups; p.cob = cout_tiles * 16; p.ncb = (on + p.cob - 1) / p.cob; p.nstages = st;
   const int es = dtype == VMG_BF16 ? 2 : 4;
   p.ss_elems = stage_stride(ks, cout_tiles, es * 8) / es;
   total = (long long)p.ncb * p.nstages * p.ss_elems;
@@ -2005,13 +2026,17 @@ static int fill_pack_ws(PackK& p, long long& total, const float* w, int O, int I
   VMG_CHECK(w && packed, "convws_pack: null pointer");
   VMG_CHECK(cout_tiles == 3 || cout_tiles == 7 || cout_tiles == 9, "convws_pack: cout_tiles must be 3, 7 or 9");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "convws_pack: nsrc must be 1..4");
-  VMG_CHECK(!transpose_flip || nsrc == 1, "convws_pack: data-gradient packing takes one K slice");
+  VMG_CHECK(!(transpose_flip & 1) || nsrc == 1, "convws_pack: data-gradient packing takes one K slice");
+  const int groups = (transpose_flip >> 8) > 1 ? (transpose_flip >> 8) : 1;
+  transpose_flip &= 1;
+  VMG_CHECK(groups == 1 || (O % groups == 0), "convws_pack: output channels must divide into the groups");
   memset(&p, 0, sizeof(p));
   VMG_CHECK(ws_plan(nsrc, src_off, src_ch, p) > 0, "convws_pack: channel slices must be multiples of 8 (and split into <= %d blocks)", MAX_ISRC);
-  const int kdim = transpose_flip ? O : I, odim = transpose_flip ? I : O;
+  const int Id = I * groups;
+  const int kdim = transpose_flip ? O : Id, odim = transpose_flip ? Id : O;
   for (int s = 0; s < p.nsrc; ++s) VMG_CHECK(p.src_off[s] >= 0 && p.src_off[s] + p.src_ch[s] <= kdim, "convws_pack: K slice out of range");
   VMG_CHECK(o0 >= 0 && on > 0 && o0 + on <= odim, "convws_pack: output slice out of range");
-  p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = 3; p.o0 = o0; p.on = on; p.transpose_flip = transpose_flip;
+  p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = 3; p.o0 = o0; p.on = on; p.transpose_flip = transpose_flip; p.groups = groups;
   p.cob = cout_tiles * 16; p.ncb = cdiv(on, p.cob);
   total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
   return 0;

@@ -69,6 +69,7 @@ def choose_tiling(M: int, cout: int, ks: int, dtype: torch.dtype, src_ch: Option
 
 
 USE_WS = True  # route eligible bf16 3x3 convs to the weight-streaming kernel (tests flip it to compare both)
+GROUPED_DENSE = True  # bf16 grouped 3x3 convolutions as ONE launch on the dense block-diagonal pack (tests / tools flip it to compare both)
 
 _WEIGHT_EPOCH = [0]
 
@@ -80,10 +81,13 @@ def bump_weight_epoch():
 
 
 def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional[Sequence[int]] = None,
-           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None, deep: int = 0, orange: Optional[Sequence[int]] = None) -> K.PackedConv:
+           i0: int = 0, on: Optional[int] = None, tiles: Optional[int] = None, deep: int = 0, orange: Optional[Sequence[int]] = None,
+           groups: int = 1) -> K.PackedConv:
     """kind 'fwd': outputs = all O, K slices = src_ch over I (padded to multiples of 8 with zero channels when
     needed).  kind 'dgrad': outputs = I[i0:i0+on), K = all O (padded to a multiple of 8).
     orange = (o0, no): one GROUP of a grouped convolution -- forward: only the outputs O[o0:o0+no); data gradient: K = O[o0:o0+no) (no % 8 == 0)."""
+    if groups > 1:
+        return _packed_grouped_dense(weight, dtype, kind, tiles, deep, groups)
     key = (id(weight), kind, dtype, tuple(src_ch) if src_ch else None, i0, on, tiles, deep == 3, tuple(orange) if orange else None)
     ver = (weight._version, _WEIGHT_EPOCH[0])
     hit = _PACK_CACHE.get(key)
@@ -151,6 +155,33 @@ def packed(weight: torch.Tensor, dtype: torch.dtype, kind: str, src_ch: Optional
     if key not in _PACK_VOLATILE and pw.call is not None and pw.call[0] == weight.data_ptr():
         _PACK_STAMP[0] += 1  # (a new or re-created pack that repack_all serves: its plan is rebuilt; packs of zero-padded copies and of
         #                       weights modified in place are redone on demand every step and never enter the plan)
+    _PACK_CACHE[key] = [ver, pw, weight]
+    return pw
+
+
+def _packed_grouped_dense(weight: torch.Tensor, dtype: torch.dtype, kind: str, tiles: Optional[int], deep: int, groups: int) -> K.PackedConv:
+    """The dense block-diagonal pack of a grouped convolution's weight (O, cg, ks, ks): 'fwd' = all O outputs over groups * cg input channels,
+    'dgrad' = all groups * cg outputs over K = O (multiples of 8).  Built from the parameter itself by the pack kernels (no dense copy), so it is
+    served by the one-launch repack like any other pack."""
+    key = (id(weight), kind, dtype, "dense", groups, tiles, deep == 3)
+    ver = (weight._version, _WEIGHT_EPOCH[0])
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2] is weight:
+        return hit[1]
+    buf0 = hit[1].buf if (hit is not None and hit[2] is weight) else None
+    w = weight.detach().contiguous()
+    O, cg = w.shape[0], w.shape[1]
+    if kind == "fwd":
+        args = dict(src_ch=[cg * groups], cout_tiles=tiles, groups=groups, out=buf0)
+    elif kind == "dgrad":
+        if O % 8:
+            raise HipError("grouped dense data-gradient pack: output channels must be a multiple of 8")
+        args = dict(transpose_flip=True, cout_tiles=tiles, groups=groups, out=buf0)
+    else:
+        raise HipError(kind)
+    pw = K.pack_conv_weight_ws(w, **args) if deep == 3 else K.pack_conv_weight(w, dtype, **args)
+    if pw.call is not None and pw.call[0] == weight.data_ptr():
+        _PACK_STAMP[0] += 1
     _PACK_CACHE[key] = [ver, pw, weight]
     return pw
 
@@ -600,12 +631,44 @@ class _GroupedConv2d(_Fn):
     gradients per tensor; reference: Mlp_cnn.fc1 with n_groups = 4, models/function.py:50-79)."""
 
     @staticmethod
+    def _group_sources(x, N, H, W, G, cg):
+        """per-group views of x for the grouped weight-gradient launch (channel counts padded to 8 through ONE padded copy when needed)"""
+        cgp = _pad_to(cg)
+        if cgp != cg:
+            xp = torch.nn.functional.pad(x.reshape(N, H, W, G, cg), (0, cgp - cg))
+            return [xp[..., g, :] for g in range(G)]
+        xf = x.reshape(N, H, W, G * cg)
+        return [xf[..., g * cg:(g + 1) * cg] for g in range(G)]
+
+    @staticmethod
     def forward(ctx, x, weight, bias, cfg):
         G, ks, act, slope, N, H, W = cfg
         O, cg = weight.shape[0], weight.shape[1]
         og, dt, M = O // G, x.dtype, N * H * W
         ctx.x_shape = tuple(x.shape)
         x = x.contiguous()
+        # Round 4: ALL groups as ONE launch on the dense block-diagonal pack (functional._packed_grouped_dense) -- G times the multiplies, a
+        # G-th of the launches, and full-width channel vectors instead of 28- / 56-channel slices: at the full configuration's stage sizes (7 x 64^2
+        # .. 7 x 8^2 pixels) the grouped launches were latency-, not FLOP-bound (profiles/r04_a_full_step_kernels.txt).  bf16, 3x3, C and O multiples of 8.
+        # (measured, tools/bench_grouped_conv.py, forward + backward: 412 -> 305 us at 7 x 64^2 x 112 ch, 334 -> 308 at 32^2 x 224, 329 -> 252 at 16^2 x 224,
+        #  but 361 -> 416 at 8^2 x 448, where the dense pack streams 4 x the weights for 448 pixels: up to 256 channels only)
+        ctx.dense = GROUPED_DENSE and dt == torch.bfloat16 and ks == 3 and (G * cg) % 8 == 0 and O % 8 == 0 and G * cg <= 256
+        if ctx.dense:
+            C = G * cg
+            tiles, mt, deep = choose_tiling(M, O, ks, dt, [C])
+            pw = packed(weight, dt, "fwd", tiles=tiles, deep=deep, groups=G)
+            need_pre = act == hip.ACT_GELU and any(ctx.needs_input_grad)
+            out, pre = K.conv_forward([x.reshape(N, H, W, C)], pw, bias, N, H, W, act=act, slope=slope, want_pre=need_pre, mt=mt, deep=deep)
+            ctx.cfg = cfg
+            ctx.has_bias = bias is not None
+            ctx.defer = DEFERRED.mode == "deferred" and isinstance(weight, torch.nn.Parameter) and ctx.needs_input_grad[1] and \
+                (bias is None or isinstance(bias, torch.nn.Parameter))
+            if ctx.defer:
+                ctx.gen = DEFERRED.note_params(*([weight] + ([bias] if bias is not None else [])))
+                ctx.bias_ref = bias
+            ctx.srcs = None
+            ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre, x)
+            return out
         cgp = _pad_to(cg)
         if cgp != cg:  # groups whose channel count is no multiple of 8 (112 / 4 = 28): ONE padded copy (N,H,W,G,cgp), group g = a strided channel slice
             xp = torch.nn.functional.pad(x.reshape(N, H, W, G, cg), (0, cgp - cg))
@@ -630,20 +693,24 @@ class _GroupedConv2d(_Fn):
             ctx.gen = DEFERRED.note_params(*([weight] + ([bias] if bias is not None else [])))
             ctx.bias_ref = bias
         ctx.srcs = srcs  # (views of x / of its padded copy: kept for the weight gradient)
-        ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre)
+        ctx.save_for_backward(weight, out if act in (hip.ACT_RELU, hip.ACT_LRELU) else None, pre, None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         G, ks, act, slope, N, H, W = ctx.cfg
-        weight, y, pre = ctx.saved_tensors
-        srcs = ctx.srcs
+        weight, y, pre, xs = ctx.saved_tensors
         O, cg = weight.shape[0], weight.shape[1]
         og, M = O // G, N * H * W
+        srcs = ctx.srcs if not ctx.dense else _GroupedConv2d._group_sources(xs, N, H, W, G, cg)
         dpre = _act_grad(dy.contiguous(), y, pre, act, slope, 1.0)
         dt = dpre.dtype
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.dense:
+            tiles, mt, deep = choose_tiling(M, G * cg, ks, dt, [O])
+            pw = packed(weight, dt, "dgrad", tiles=tiles, deep=deep, groups=G)
+            dx, _ = K.conv_forward([dpre], pw, None, N, H, W, mt=mt, deep=deep)
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty((N, H, W, G * cg), dtype=dt, device=dy.device)
             tiles, mt, deep = choose_tiling(M, cg, ks, dt, [og])
             for g in range(G):

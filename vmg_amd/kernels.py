@@ -50,9 +50,11 @@ class PackedConv:
 
 def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Sequence[int]] = None,
                      src_off: Optional[Sequence[int]] = None, o0: int = 0, on: Optional[int] = None,
-                     transpose_flip: bool = False, out: Optional[torch.Tensor] = None, cout_tiles: Optional[int] = None) -> PackedConv:
+                     transpose_flip: bool = False, out: Optional[torch.Tensor] = None, cout_tiles: Optional[int] = None, groups: int = 1) -> PackedConv:
     """w: fp32 (O, I, KS, KS) or (O, I).  Forward pack: K slices = src_off/src_ch over I, outputs O[o0:o0+on).
-    Data-gradient pack (transpose_flip): outputs I[o0:o0+on), K = O[src_off[0]:+src_ch[0])."""
+    Data-gradient pack (transpose_flip): outputs I[o0:o0+on), K = O[src_off[0]:+src_ch[0]).
+    groups > 1: w is the weight of a GROUPED convolution (I = channels per group); the pack is its dense block-diagonal operator over
+    groups * I input channels, so that one launch serves all groups."""
     hip.require_cuda(w)
     if w.dtype != torch.float32 or not w.is_contiguous():
         raise HipError("pack_conv_weight expects a contiguous fp32 weight")
@@ -62,7 +64,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
         O, I, ks = w.shape[0], w.shape[1], w.shape[2]
     else:
         raise HipError(f"unsupported weight shape {tuple(w.shape)}")
-    kdim, odim = (O, I) if transpose_flip else (I, O)
+    kdim, odim = (O, I * groups) if transpose_flip else (I * groups, O)
     if src_ch is None:
         src_ch, src_off = [kdim], [0]
     if src_off is None:
@@ -73,6 +75,7 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
     if on is None:
         on = odim - o0
     tiles = cout_tiles if cout_tiles else cout_tiles_for(on, dtype, ks)
+    flag = (1 if transpose_flip else 0) | ((groups << 8) if groups > 1 else 0)
     code = hip.dtype_code(dtype)
     l = hip.lib()
     nbytes = l.vmg_conv_pack_bytes(code, ks, on, len(src_ch), _intarr(src_ch), tiles)
@@ -83,8 +86,8 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
     elif out.numel() * out.element_size() < nbytes:
         raise HipError("pack buffer too small")
     hip.check(l.vmg_conv_pack(code, w.data_ptr(), O, I, ks, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch),
-                              1 if transpose_flip else 0, tiles, out.data_ptr(), hip.stream_ptr()), "vmg_conv_pack")
-    return PackedConv(out, dtype, ks, on, src_ch, tiles, call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), 1 if transpose_flip else 0))
+                              flag, tiles, out.data_ptr(), hip.stream_ptr()), "vmg_conv_pack")
+    return PackedConv(out, dtype, ks, on, src_ch, tiles, call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), flag))
 
 
 def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -> int:
@@ -108,14 +111,15 @@ def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -
 
 
 def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None, src_off: Optional[Sequence[int]] = None, o0: int = 0,
-                        on: Optional[int] = None, transpose_flip: bool = False, cout_tiles: int = 9, out: Optional[torch.Tensor] = None) -> PackedConv:
+                        on: Optional[int] = None, transpose_flip: bool = False, cout_tiles: int = 9, out: Optional[torch.Tensor] = None,
+                        groups: int = 1) -> PackedConv:
     """bf16 pack of a 3x3 weight (O, I, 3, 3) for the weight-streaming kernel (same slicing conventions as pack_conv_weight).
     out: an existing pack buffer of this very pack to rewrite in place."""
     hip.require_cuda(w)
     if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
         raise HipError("pack_conv_weight_ws expects a contiguous fp32 (O, I, 3, 3) weight")
     O, I = w.shape[0], w.shape[1]
-    kdim, odim = (O, I) if transpose_flip else (I, O)
+    kdim, odim = (O, I * groups) if transpose_flip else (I * groups, O)
     if src_ch is None:
         src_ch, src_off = [kdim], [0]
     if src_off is None:
@@ -125,6 +129,7 @@ def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None,
             acc += c
     if on is None:
         on = odim - o0
+    flag = (1 if transpose_flip else 0) | ((groups << 8) if groups > 1 else 0)
     l = hip.lib()
     nbytes = l.vmg_convws_pack_bytes(on, len(src_ch), _intarr(src_ch), cout_tiles)
     if nbytes <= 0:
@@ -133,10 +138,10 @@ def pack_conv_weight_ws(w: torch.Tensor, src_ch: Optional[Sequence[int]] = None,
         out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     elif out.numel() * out.element_size() < nbytes:
         raise HipError("pack buffer too small")
-    hip.check(l.vmg_convws_pack(w.data_ptr(), O, I, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch), 1 if transpose_flip else 0,
+    hip.check(l.vmg_convws_pack(w.data_ptr(), O, I, o0, on, len(src_ch), _intarr(src_off), _intarr(src_ch), flag,
                                 cout_tiles, out.data_ptr(), hip.stream_ptr()), "vmg_convws_pack")
     return PackedConv(out, torch.bfloat16, 3, on, src_ch, cout_tiles, layout="ws",
-                      call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), 1 if transpose_flip else 0))
+                      call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), flag))
 
 
 # vmg_conv_desc as one struct format (checked against the ctypes layout at import): field order of hip.ConvDesc
