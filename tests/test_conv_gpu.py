@@ -399,7 +399,7 @@ def test_conv_weights_stationary_variant(case):
 
 # ---------------------------------------------------------------------------------------------- weight-streaming kernel
 @pytest.mark.parametrize("shape", [(2, 24, 20, 144, 144), (8, 64, 64, 144, 144), (3, 9, 17, 128, 144), (1, 16, 16, 144, 288), (1, 8, 8, 112, 224),
-                                   (2, 20, 33, 224, 112), (1, 12, 16, 448, 112), (1, 30, 50, 32, 144)])
+                                   (2, 20, 33, 224, 112), (1, 12, 16, 448, 112), (1, 30, 50, 32, 144), (2, 20, 36, 144, 256), (1, 9, 17, 64, 128)])
 def test_conv_ws_bias_relu(shape):
     """vmg_conv_fwd deep = 3 (128-pixel tiles, loader waves stream the weights through an LDS ring) vs the oracle; shapes cover
     ragged image borders, both channel-block kinds (multiples of 32, and 16 left over), several channel blocks per source
@@ -412,7 +412,7 @@ def test_conv_ws_bias_relu(shape):
     b = R.seeded((Co,), 43, 0.1)
     want = F.relu(O.conv_nhwc(_q(x, dtype), _q(w, dtype), b, 1))
     tiles = K.ws_eligible(Co, 3, dtype, [Ci])
-    assert tiles in (7, 9)
+    assert tiles in (7, 8, 9)
     pw = K.pack_conv_weight_ws(w.cuda(), cout_tiles=tiles)
     got, _ = K.conv_forward([x.cuda().to(dtype)], pw, b.cuda(), N, H, W, act=hip.ACT_RELU, deep=3)
     _cmp(got, want, dtype, f"conv ws {shape}")

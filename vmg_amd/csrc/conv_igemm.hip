@@ -1233,7 +1233,7 @@ struct WsItems {
   static constexpr int C8 = 2 * NCT, TOTAL = 128 * C8, THREADS = WsGeo<NCT>::THREADS, NIT = (TOTAL + THREADS - 1) / THREADS;
   static constexpr int PSTR = NCT * 64 + 16;  // bytes per pixel in the patch
   __device__ static __forceinline__ void decode(int j, int& pxl, int& c8) {
-    pxl = NCT == 9 ? (j * 3641) >> 16 : (NCT == 7 ? (j * 4682) >> 16 : (j * 10923) >> 16);  // j / 18, j / 14, j / 6 (exact for j < 4000)
+    pxl = NCT == 9 ? (j * 3641) >> 16 : (NCT == 7 ? (j * 4682) >> 16 : (NCT == 8 ? j >> 4 : (j * 10923) >> 16));  // j / 18, j / 14, j / 16, j / 6 (exact for j < 4000)
     c8 = j - pxl * C8;
   }
 };
@@ -2024,7 +2024,7 @@ extern "C" int64_t vmg_convws_pack_bytes(int on, int nsrc, const int* src_ch, in
 static int fill_pack_ws(PackK& p, long long& total, const float* w, int O, int I, int o0, int on, int nsrc, const int* src_off, const int* src_ch,
                         int transpose_flip, int cout_tiles, void* packed) {
   VMG_CHECK(w && packed, "convws_pack: null pointer");
-  VMG_CHECK(cout_tiles == 3 || cout_tiles == 7 || cout_tiles == 9, "convws_pack: cout_tiles must be 3, 7 or 9");
+  VMG_CHECK(cout_tiles == 3 || cout_tiles == 7 || cout_tiles == 8 || cout_tiles == 9, "convws_pack: cout_tiles must be 3, 7, 8 or 9");
   VMG_CHECK(nsrc >= 1 && nsrc <= 4, "convws_pack: nsrc must be 1..4");
   VMG_CHECK(!(transpose_flip & 1) || nsrc == 1, "convws_pack: data-gradient packing takes one K slice");
   const int groups = (transpose_flip >> 8) > 1 ? (transpose_flip >> 8) : 1;
@@ -2148,7 +2148,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->deep == 3) {
     // weight-streaming kernel: 8 x 16 pixel tiles, dense halo, its own packed layout (vmg_convws_pack)
-    VMG_CHECK(d->dtype == VMG_BF16 && d->ks == 3 && k.vec8 && (ntb == 3 || ntb == 7 || ntb == 9), "conv_fwd: the weight-streaming kernel is bf16 3x3 with 16-byte aligned rows, cout_tiles 3, 7 or 9");
+    VMG_CHECK(d->dtype == VMG_BF16 && d->ks == 3 && k.vec8 && (ntb == 3 || ntb == 7 || ntb == 8 || ntb == 9), "conv_fwd: the weight-streaming kernel is bf16 3x3 with 16-byte aligned rows, cout_tiles 3, 7, 8 or 9");
     for (int s = 0; s < n; ++s) VMG_CHECK(k.src_ch[s] % 16 == 0, "conv_fwd: the weight-streaming kernel takes channel blocks that are multiples of 16 (got %d)", k.src_ch[s]);
     int kt3 = 0, halo3 = 0;
     for (int s = 0; s < n; ++s) {
@@ -2161,7 +2161,7 @@ extern "C" int vmg_conv_fwd(const vmg_conv_desc* d, void* stream) {
     k.nstages = kt3;
     k.halo_bytes = (halo3 + 1023) & ~1023;  // whole 1-KiB LDS-DMA pieces
     k.tiles_y = cdiv(d->H, 8);
-    return ntb == 9 ? launch_ws<9>(k, ncb, st) : (ntb == 7 ? launch_ws<7>(k, ncb, st) : launch_ws<3>(k, ncb, st));
+    return ntb == 9 ? launch_ws<9>(k, ncb, st) : (ntb == 7 ? launch_ws<7>(k, ncb, st) : (ntb == 8 ? launch_ws<8>(k, ncb, st) : launch_ws<3>(k, ncb, st)));
   }
   if (d->deep == 6 && d->dtype == VMG_BF16 && d->ks == 3 && mt == 1 && k.vec8 && n == 1 && (ntb == 1 || ntb == 3 || ntb == 4) && k.src_ch[0] <= 64 && k.src_ch[0] % 8 == 0 &&
       k.src_ps[0] % 8 == 0 && d->W <= 255 * 16 && (long long)d->W * k.src_ps[0] * 2 * 10 < (1ll << 31)) {

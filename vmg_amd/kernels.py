@@ -6,6 +6,7 @@ stream.  Shapes are validated on the host before a kernel is launched.
 from __future__ import annotations
 
 import ctypes
+import os
 import struct
 from typing import Optional, Sequence, Tuple
 
@@ -90,8 +91,11 @@ def pack_conv_weight(w: torch.Tensor, dtype: torch.dtype, src_ch: Optional[Seque
     return PackedConv(out, dtype, ks, on, src_ch, tiles, call=(w.data_ptr(), O, I, o0, on, list(src_off), list(src_ch), flag))
 
 
+WS_128_BLOCKS = os.environ.get("VMG_WS_128", "1") != "0"  # A/B switch of the 128-channel-block weight-streaming route
+
+
 def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -> int:
-    """cout_tiles (9 or 7) if the weight-streaming kernel covers this conv (bf16, 3x3, output channels in blocks of 144 or 112,
+    """cout_tiles (9, 7 or 8) if the weight-streaming kernel covers this conv (bf16, 3x3, output channels in blocks of 144, 112 or 128,
     source channel counts that split into blocks of <= 160 channels that are multiples of 16), else 0."""
     if dtype != torch.bfloat16 or ks != 3:
         return 0
@@ -107,6 +111,8 @@ def ws_eligible(cout: int, ks: int, dtype: torch.dtype, src_ch: Sequence[int]) -
         return 9
     if cout % 112 == 0:
         return 7
+    if cout % 128 == 0 and WS_128_BLOCKS:
+        return 8  # (round 4: `upconv2`, 144 -> 256 before the second PixelShuffle: 128-channel blocks)
     return 0
 
 
