@@ -243,6 +243,10 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
  *                    rounding); frames = contiguous blocks of frame_elems elements (whole 16-byte vectors).  The two direction sweeps of
  *                    the recurrence (models/trajectory.py:323-392, 407-477) run as one batch: step j works on [frame t-1-j | frame j] of
  *                    every clip -- that arrangement of the (n, t) features is one gather, its gradient one gather-add.
+ * vmg_pair_steps     the same pairing through a POINTER LIST of the t step tensors (2n frames each; the recurrence's step outputs / step
+ *                    gradients are separate allocations): mode 0 steps -> a = backward-sweep features, b = forward-sweep features, both (n, t)
+ *                    in frame order (trajectory.py:394-395, 479: `feats_.insert(0, ...)` / `append` + stack); mode 1 the inverse (its
+ *                    backward); mode 2 a[i, f] = steps[t-1-f][i] + steps[f][n+i] (the gradient of the pairing, fp32 sum, one rounding).  t <= 64.
  * vmg_layernorm_fwd  y = (x - mean) * rstd * w + b over the last dim C of (M, C) rows, eps inside the sqrt; mean / rstd
  *                    (fp32, M each) are written when non-null.  nn.LayerNorm at function.py:1164,1195; layers.py:768-775;
  *                    swin_3d.py:717,741.
@@ -251,6 +255,7 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
 int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
                 void* stream);
 int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream);
+int vmg_pair_steps(int dtype, int mode, void* const* steps, void* a, void* b, int n, int t, int64_t frame_elems, void* stream);
 int vmg_frame_gather(int dtype, const void* src, void* dst, const int* idx, int64_t frame_elems, int n_src_frames, int n_dst_frames, int nsrc,
                      void* stream);
 int vmg_pixel_unshuffle_actgrad(int dtype, const void* dy, const void* ref, void* out, int N, int H, int W, int c, int act, float slope,

@@ -209,6 +209,33 @@ def test_drop_path_plan_matches_per_call_semantics():
     FH.DROP.begin(res.device, False)
 
 
+def test_drop_path_plan_with_calls_of_different_shapes():
+    """The full configuration's stages differ in channel count (112 / 224 / 448) and its residual sites alternate between residual_drop_path
+    and gate_residual: the plan must cover such a sequence too (round 4: one flat coefficient buffer), not fall back to four tiny kernels per call."""
+    from vmg_amd import functional as FH
+    shapes = [(3, 16), (3, 32), (5, 32), (3, 16)]
+    calls = [(0.25, 1.0), (0.5, 0.5), (0.1, 1.0), (0.4, 2.0)]
+    ts = [(torch.zeros(B, 2, 4, 4, C, device="cuda", dtype=torch.bfloat16), torch.ones(B, 2, 4, 4, C, device="cuda", dtype=torch.bfloat16)) for B, C in shapes]
+    zeros_seen = 0
+    for rnd in range(4):
+        FH.DROP.begin(ts[0][0].device, True)
+        for i, ((p, s), (res, y)) in enumerate(zip(calls, ts)):
+            if i % 2:
+                out = FH.gate_residual(y, torch.zeros_like(y) + 0.5, res, p, True, s).float() / (1.5 * float(torch.tanh(torch.tensor(0.5))))
+            else:
+                out = FH.residual_drop_path(res, y, p, True, s).float()
+            per = out.reshape(out.shape[0], -1)
+            assert bool((per == per[:, :1]).all())
+            v = per[:, 0]
+            want = s / (1.0 - p)
+            assert bool(((v == 0) | ((v - want).abs() <= 2e-2 * want)).all()), (rnd, i, v, want)
+            zeros_seen += int((v == 0).sum())
+        if rnd >= 1:
+            assert FH.DROP.plan is not None and FH.DROP.g is not None and FH.DROP.idx == len(calls)
+    assert zeros_seen > 0  # (56 draws with drop probabilities 0.1 .. 0.5)
+    FH.DROP.begin(ts[0][0].device, False)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("axis", ["h", "w"])
 @pytest.mark.parametrize("geom", [(1, 2, 16, 16, 224, 12, 228), (1, 3, 32, 32, 224, 16, 224), (2, 1, 8, 8, 448, 8, 448), (1, 2, 10, 7, 40, 4, 44), (1, 1, 5, 9, 16, 3, 18)])

@@ -168,6 +168,46 @@ def test_pair_frames_is_transpose_flip_cat_and_its_gradient(dtype, n, t):
         assert torch.equal(x.grad, ref.to(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,t", [(1, 1), (2, 5), (4, 7)])
+def test_step_tensors_of_the_lockstep_sweeps_fwd_bwd(dtype, n, t):
+    """functional.pair_frame_steps / unpair_steps (vmg_pair_steps, round 4): the recurrence's per-step tensors as separate allocations.
+    pair_frame_steps(x)[j] = pair_frames(x)[j] and its gradient = the sum of the two step gradients per frame (fp32 sum, one rounding);
+    unpair_steps(steps) = the reference's frame-ordered stacks of the two sweeps (trajectory.py:394-395, 479) and its gradient the matching
+    halves -- against the torch spelling (split / reversed / stack), bit-exact."""
+    from vmg_amd import functional as FH
+    g = torch.Generator(device="cuda").manual_seed(12)
+    x = torch.randn((n, t, 6, 5, 16), generator=g, device="cuda").to(dtype).requires_grad_(True)
+    steps = FH.pair_frame_steps(x)
+    want = FH.pair_frames(x.detach())
+    assert len(steps) == t and all(torch.equal(s, w) for s, w in zip(steps, want.unbind(0)))
+    gos = [torch.randn(steps[0].shape, generator=g, device="cuda").to(dtype) for _ in range(t)]
+    torch.autograd.backward(list(steps), gos)
+    go = torch.stack(gos, 0).float()
+    ref = (go[:, :n].flip(0) + go[:, n:]).transpose(0, 1)
+    assert torch.equal(x.grad, ref.to(dtype))
+
+    feats = [torch.randn((2 * n, 6, 5, 16), generator=g, device="cuda").to(dtype).requires_grad_(True) for _ in range(t)]
+    back, fwd = FH.unpair_steps(feats, n)
+    fr = [f.detach().clone().requires_grad_(True) for f in feats]
+    halves = [f.split(n, 0) for f in fr]
+    wback = torch.stack([hv[0] for hv in reversed(halves)], 1)
+    wfwd = torch.stack([hv[1] for hv in halves], 1)
+    assert torch.equal(back, wback) and torch.equal(fwd, wfwd)
+    gb = torch.randn(back.shape, generator=g, device="cuda").to(dtype)
+    gf = torch.randn(fwd.shape, generator=g, device="cuda").to(dtype)
+    torch.autograd.backward([back, fwd], [gb, gf])
+    torch.autograd.backward([wback, wfwd], [gb, gf])
+    for a, b in zip(feats, fr):
+        assert torch.equal(a.grad, b.grad)
+    # only one of the two outputs used: the other half of every step gradient is zero
+    feats2 = [f.detach().clone().requires_grad_(True) for f in feats]
+    b2, _ = FH.unpair_steps(feats2, n)
+    b2.backward(gb)
+    for j, f in enumerate(feats2):
+        assert torch.equal(f.grad[:n], gb[:, t - 1 - j]) and float(f.grad[n:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(3, 1, 1, 2), (2, 2, 2, 2), (2, 5, 3, 2), (4, 16, 16, 2), (1, 32, 20, 4)])
 def test_flow_upsampling_x2_align_corners_fwd_bwd(shape):
     """SPyNet's flow between pyramid levels (models/vmg.py:97-102): scale * F.interpolate(flow, scale_factor=2, mode='bilinear',

@@ -538,6 +538,49 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const T* __restrict__
     }
   }
 }
+// The step tensors of the lock-step recurrence, addressed through a POINTER LIST (the t step tensors are separate allocations: the residual chain
+// of step j writes its own output).  Step j holds 2n frames: rows [0, n) = the backward sweep at frame t-1-j, rows [n, 2n) = the forward sweep at
+// frame j of every clip.
+//   mode 0: steps -> back, fwd (n, t) in frame order         (torch: t splits, two stacks over 2t views)
+//   mode 1: back, fwd -> steps                               (its backward: t concatenations)
+//   mode 2: steps -> a (n, t):  a[i, f] = steps[t-1-f][i] + steps[f][n+i]   (fp32 sum, one rounding: the backward of frame_gather's pairing, without the stack
+//                                                                            autograd builds from the t step gradients first)
+constexpr int PS_MAX_T = 64;
+struct PairStepsK {
+  void* step[PS_MAX_T];
+  void* a;
+  void* b;
+  int n, t, chunks, mode;
+  long long fv;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pair_steps_kernel(const PairStepsK k) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  typedef VecN<T, VN> Vec;
+  const int f = blockIdx.x / k.chunks, ck = blockIdx.x - f * k.chunks;
+  const long long v0 = k.fv * ck / k.chunks, v1 = k.fv * (ck + 1) / k.chunks;
+  if (k.mode == 2) {
+    const int i = f / k.t, fr = f - i * k.t;  // dst frame (clip i, frame fr)
+    const Vec* s0 = reinterpret_cast<const Vec*>(k.step[k.t - 1 - fr]) + (long long)i * k.fv;
+    const Vec* s1 = reinterpret_cast<const Vec*>(k.step[fr]) + (long long)(k.n + i) * k.fv;
+    Vec* d = reinterpret_cast<Vec*>(k.a) + (long long)f * k.fv;
+    for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
+      const Vec x = s0[v], y = s1[v];
+      Vec o;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) o.v[e] = from_f32<T>(to_f32(x.v[e]) + to_f32(y.v[e]));
+      d[v] = o;
+    }
+    return;
+  }
+  const int j = f / (2 * k.n), r = f - j * 2 * k.n;  // step j, row r
+  Vec* st = reinterpret_cast<Vec*>(k.step[j]) + (long long)r * k.fv;
+  Vec* ot = r < k.n ? reinterpret_cast<Vec*>(k.a) + ((long long)r * k.t + (k.t - 1 - j)) * k.fv
+                    : reinterpret_cast<Vec*>(k.b) + ((long long)(r - k.n) * k.t + j) * k.fv;
+  const Vec* src = k.mode == 0 ? st : ot;
+  Vec* dst = k.mode == 0 ? ot : st;
+  for (long long v = v0 + threadIdx.x; v < v1; v += 256) dst[v] = src[v];
+}
 }  // namespace
 
 extern "C" int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
@@ -573,6 +616,30 @@ extern "C" int vmg_frame_gather(int dtype, const void* src, void* dst, const int
   if (dtype == VMG_BF16) { if (nsrc == 1) FG_LAUNCH(bf16, 1); else FG_LAUNCH(bf16, 2); }
   else { if (nsrc == 1) FG_LAUNCH(float, 1); else FG_LAUNCH(float, 2); }
 #undef FG_LAUNCH
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_pair_steps(int dtype, int mode, void* const* steps, void* a, void* b, int n, int t, int64_t frame_elems, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "pair_steps: bad dtype");
+  VMG_CHECK(steps && a && (b || mode == 2) && n > 0 && t > 0 && t <= PS_MAX_T && frame_elems > 0 && mode >= 0 && mode <= 2, "pair_steps: bad arguments (t <= %d)", PS_MAX_T);
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(frame_elems % vn == 0 && ((uintptr_t)a | (uintptr_t)b) % 16 == 0, "pair_steps: frames must be whole 16-byte vectors, tensors 16-byte aligned");
+  PairStepsK k;
+  for (int j = 0; j < t; ++j) {
+    VMG_CHECK(steps[j] && (uintptr_t)steps[j] % 16 == 0, "pair_steps: step %d: null or unaligned", j);
+    k.step[j] = steps[j];
+  }
+  k.a = a; k.b = b; k.n = n; k.t = t; k.mode = mode;
+  k.fv = frame_elems / vn;
+  const long long frames = mode == 2 ? (long long)n * t : 2LL * n * t;
+  long long chunks = cdiv64(2048, frames);  // ~2 048 blocks in all
+  if (chunks > cdiv64(k.fv, 256)) chunks = cdiv64(k.fv, 256);
+  if (chunks < 1) chunks = 1;
+  k.chunks = (int)chunks;
+  const dim3 grid((unsigned)(frames * chunks));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(pair_steps_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(pair_steps_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, k);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -1128,6 +1128,61 @@ def pair_frames(x: torch.Tensor) -> torch.Tensor:
     return _PairFrames.apply(x)
 
 
+class _PairFrameSteps(_Fn):
+    @staticmethod
+    def forward(ctx, x):
+        n, t = x.shape[:2]
+        ctx.n, ctx.t, ctx.shape = n, t, tuple(x.shape)
+        fi, _ = _pair_index(n, t, x.device)
+        return tuple(K.frame_gather(x.contiguous(), fi, 2 * n * t, tuple(x.shape[2:])).view(t, 2 * n, *x.shape[2:]).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, t = ctx.n, ctx.t
+        ref = next(g for g in gs if g is not None)
+        gs = [torch.zeros_like(ref) if g is None else g.contiguous() for g in gs]
+        dx = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        K.pair_steps(2, gs, dx, None, n, t)
+        return dx
+
+
+def pair_frame_steps(x: torch.Tensor):
+    """pair_frames as a tuple of its t step tensors: the step gradients (separate allocations, one per recurrence step) are summed straight into dx by
+    one kernel -- `pair_frames(x).unbind(0)` made autograd stack them into one (t, 2n, ...) tensor first (66 MB at the bench shape)."""
+    return _PairFrameSteps.apply(x)
+
+
+class _UnpairSteps(_Fn):
+    @staticmethod
+    def forward(ctx, n, *steps):
+        t = len(steps)
+        steps = [s.contiguous() for s in steps]
+        frame = tuple(steps[0].shape[1:])
+        back = torch.empty((n, t, *frame), dtype=steps[0].dtype, device=steps[0].device)
+        fwd = torch.empty_like(back)
+        K.pair_steps(0, steps, back, fwd, n, t)
+        ctx.n, ctx.t, ctx.frame = n, t, frame
+        return back, fwd
+
+    @staticmethod
+    def backward(ctx, dback, dfwd):
+        n, t = ctx.n, ctx.t
+        ref = dback if dback is not None else dfwd
+        dback = torch.zeros((n, t, *ctx.frame), dtype=ref.dtype, device=ref.device) if dback is None else dback.contiguous()
+        dfwd = torch.zeros_like(dback) if dfwd is None else dfwd.contiguous()
+        buf = torch.empty((t, 2 * n, *ctx.frame), dtype=ref.dtype, device=ref.device)
+        gs = buf.unbind(0)
+        K.pair_steps(1, gs, dback, dfwd, n, t)
+        return (None, *gs)
+
+
+def unpair_steps(steps: Sequence[torch.Tensor], n: int):
+    """The t step outputs of the lock-step recurrence ((2n, ...) each: rows [0, n) the backward sweep at frame t-1-j, rows [n, 2n) the forward sweep at
+    frame j) -> (back, fwd), both (n, t, ...) in frame order (models/trajectory.py:394-395 `insert(0, ...)`, :479 `append`, then the stacks): one kernel
+    each way instead of t splits + two stacks forward and t concatenations backward."""
+    return _UnpairSteps.apply(n, *steps)
+
+
 def morph_tokens(x: torch.Tensor, axis: str, chunk: int, Cp: int) -> torch.Tensor:
     """Token layout of the H-/W-branch (models/function.py:763-764, 776-777): pad C->Cp and the mixed axis to a
     multiple of `chunk`; token (group, k) gets features f = p*S + s <- x[position p of the group, channel k*S + s]."""
@@ -1316,24 +1371,33 @@ class _DropPlan:
     deviation from the recorded sequence falls back to the per-call path."""
 
     def __init__(self):
-        self.rec, self.plan, self.g, self.gb, self.idx, self.consts = [], None, None, None, 0, {}
+        self.rec, self.plan, self.g, self.gb, self.idx, self.consts, self.offs = [], None, None, None, 0, {}, []
 
     def begin(self, device, active: bool):
         rec, self.rec = self.rec, []
         self.idx, self.g, self.gb, self.plan = 0, None, None, None
-        if not active or not rec or any(r[:2] != rec[0][:2] for r in rec) or any(r[2] <= 0.0 for r in rec):
+        if not active or not rec or any(r[2] <= 0.0 for r in rec):
             return
         key = (tuple(rec), str(device))
         c = self.consts.get(key)
         if c is None:
-            keep = torch.tensor([r[2] for r in rec], dtype=torch.float32, device=device).reshape(-1, 1, 1)
-            mult = torch.tensor([r[3] / r[2] for r in rec], dtype=torch.float32, device=device).reshape(-1, 1, 1)
-            c = self.consts[key] = (keep, mult)
+            # one row of constants per (call, sample); `rows` expands a call's per-sample coefficients over its channels -- the calls of a pass
+            # may differ in batch and channel count (the stages of the full configuration: 112 / 224 / 448 channels), so the coefficients
+            # live in ONE flat buffer, call i at offs[i] as (B_i, C_i)
+            keep = torch.tensor([r[2] for r in rec for _ in range(r[0])], dtype=torch.float32, device=device)
+            mult = torch.tensor([r[3] / r[2] for r in rec for _ in range(r[0])], dtype=torch.float32, device=device)
+            rows, offs, row0, off = [], [], 0, 0
+            for B, C, _, _ in rec:
+                rows.append((torch.arange(B, dtype=torch.int64) + row0).repeat_interleave(C))
+                offs.append(off)
+                row0 += B
+                off += B * C
+            c = self.consts[key] = (keep, mult, torch.cat(rows).to(device), offs)
             if len(self.consts) > 8:
                 self.consts.pop(next(iter(self.consts)))
-        B, C = rec[0][:2]
-        u = torch.rand(len(rec), B, 1, device=device)
-        self.g = ((u < c[0]).to(torch.float32) * c[1]).expand(len(rec), B, C).contiguous()
+        u = torch.rand(c[0].numel(), device=device)
+        self.g = ((u < c[0]).to(torch.float32) * c[1]).index_select(0, c[2])
+        self.offs = c[3]
         self.plan = rec
 
     def take(self, B, C, keep, scale, dtype):
@@ -1345,7 +1409,8 @@ class _DropPlan:
             return None, None
         if self.gb is None or self.gb.dtype != dtype:
             self.gb = self.g.to(dtype)
-        return self.g[i], self.gb[i]
+        o = self.offs[i]
+        return self.g[o:o + B * C].view(B, C), self.gb[o:o + B * C].view(B, C)
 
 
 DROP = _DropPlan()

@@ -369,6 +369,23 @@ def frame_gather(src: torch.Tensor, idx: torch.Tensor, n_dst: int, frame_shape) 
     return dst
 
 
+def pair_steps(mode: int, steps: Sequence[torch.Tensor], a: torch.Tensor, b: Optional[torch.Tensor], n: int, t: int) -> None:
+    """vmg_pair_steps: the t step tensors of the lock-step recurrence ((2n, *frame) each, separate allocations) <-> a, b = the two sweeps' features
+    (n, t, *frame) in frame order.  mode 0: steps -> a, b; mode 1: a, b -> steps; mode 2: a[i, f] = steps[t-1-f][i] + steps[f][n+i] (b unused)."""
+    hip.require_cuda(a, b, *steps)
+    if len(steps) != t or t < 1 or a.shape[0] != n or a.shape[1] != t or not a.is_contiguous():
+        raise HipError("pair_steps: t step tensors and a contiguous (n, t, ...) tensor expected")
+    fe = a.numel() // (n * t)
+    for st in steps:
+        if st.dtype != a.dtype or st.numel() != 2 * n * fe or not st.is_contiguous():
+            raise HipError("pair_steps: every step tensor must be contiguous (2n, *frame) of the same dtype")
+    if mode != 2 and (b is None or b.shape != a.shape or b.dtype != a.dtype or not b.is_contiguous()):
+        raise HipError("pair_steps: the second (n, t, ...) tensor must match the first")
+    ptrs = (ctypes.c_void_p * t)(*[st.data_ptr() for st in steps])
+    hip.check(hip.lib().vmg_pair_steps(hip.dtype_code(a.dtype), mode, ptrs, a.data_ptr(), b.data_ptr() if b is not None else None, n, t, fe, hip.stream_ptr()),
+              "vmg_pair_steps")
+
+
 def pixel_unshuffle_actgrad(dy: torch.Tensor, ref: Optional[torch.Tensor], N: int, H: int, W: int, act: int, slope: float, alpha: float) -> torch.Tensor:
     """(N,2H,2W,c) gradient (and activation reference) -> (N,H,W,4c) pre-activation gradient of a PixelShuffle conv, one pass."""
     hip.require_cuda(dy, ref)

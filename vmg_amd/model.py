@@ -388,7 +388,7 @@ class Trajectory_multi_head(nn.Module):
         fb = flows_backward.permute(1, 0, 3, 4, 2).float()
         ff = flows_forward.permute(1, 0, 3, 4, 2).float()
         s = self.keyframe_stride
-        xpair = FH.pair_frames(x)  # (t, 2n, h, w, c): step j -> [frame t-1-j | frame j], one gather from the batch-major features
+        curs = FH.pair_frame_steps(x)  # t tensors (2n, h, w, c): step j -> [frame t-1-j | frame j], one gather from the batch-major features
         # step j >= 1 warps by flows_backward[:, t-1-j] (backward sweep) and flows_forward[:, j-1] (forward sweep)
         flpair = torch.cat([fb.flip(0), ff], 1).contiguous() if t > 1 else None  # (t-1, 2n, h, w, 2); row j-1 serves step j
         ident = FH.identity_grid(2 * n, h, w, x.device)
@@ -397,9 +397,8 @@ class Trajectory_multi_head(nn.Module):
         k_in: List[torch.Tensor] = []
         k_state: List[torch.Tensor] = []
         feats = []
-        # unbind / split instead of indexing: the backward of x[j] is a zero-filled tensor of the WHOLE stack per frame (66 MB each at the
-        # bench shape) summed pairwise by autograd; the backward of unbind is one stack
-        curs = xpair.unbind(0)
+        # (unbind instead of indexing: the backward of fl[j] is a zero-filled tensor of the WHOLE stack per frame, summed pairwise by autograd; the
+        # backward of unbind is one stack.  The features' step tensors come from / go to one kernel each way: pair_frame_steps, unpair_steps.)
         fls = flpair.unbind(0) if flpair is not None else ()
         for j in range(t):
             cur = curs[j]
@@ -417,10 +416,9 @@ class Trajectory_multi_head(nn.Module):
                 k_state.append(FH.grad_bank(feat))
                 k_in.append(FH.grad_bank(cur))
             feats.append(feat)
-        halves = [f.split(n, 0) for f in feats]  # step j: (backward sweep at frame t-1-j, forward sweep at frame j)
-        # the fusion is a 1x1 conv: its pixels may come in any order -- batch-major like x, so neither x nor the result is transposed
-        back = torch.stack([hv[0] for hv in reversed(halves)], 1)  # (n, t, h, w, c), frame order
-        fwd = torch.stack([hv[1] for hv in halves], 1)
+        # step j: (backward sweep at frame t-1-j, forward sweep at frame j) -> both sweeps (n, t, h, w, c) in frame order.  The fusion is a 1x1 conv:
+        # its pixels may come in any order -- batch-major like x, so neither x nor the result is transposed
+        back, fwd = FH.unpair_steps(feats, n)
         out = conv(self.fusion, [back, x, fwd], n * t, h, w, act=ACT_LRELU, slope=0.1)
         return out.reshape(n, t, h, w, c)
 
