@@ -425,6 +425,13 @@ int vmg_se_mlp_bwd(const float* dout, const float* out, const float* m, const fl
 int vmg_avgpool2_nhwc(int dtype, const void* x, void* y, int n, int h, int w, int c, void* stream);
 int vmg_upsample2x_ac_fwd(const float* x, float* y, int n, int h, int w, int c, float scale, void* stream);
 int vmg_upsample2x_ac_bwd(const float* dy, float* dx, int n, int h, int w, int c, float scale, void* stream);
+/* The glue of one SPyNet pyramid level (models/vmg.py:72-85) on this port's 8-channel pixels (RGB in channels 0..2):
+ * vmg_spy_operand_fwd  out (npix, 8) = [ref[..., 0:3] | warped[..., 0:3] | (T) up (npix, 2) fp32]  -- `torch.cat([ref, warp(supp, flow_up), flow_up], 1)`
+ * vmg_spy_operand_bwd  dwarped (npix, 8) = [dx8[..., 3:6] | 0 x 5], dup (npix, 2) fp32 = dx8[..., 6:8]
+ * vmg_spy_flow_add     out fp32 = up fp32 + (float) res (n elements)                               -- `flow = flow_up + basic_module(...)` */
+int vmg_spy_operand_fwd(int dtype, const void* ref, const void* warped, const float* up, void* out, int64_t npix, void* stream);
+int vmg_spy_operand_bwd(int dtype, const void* dx8, void* dwarped, float* dup, int64_t npix, void* stream);
+int vmg_spy_flow_add(int dtype, const float* up, const void* res, float* out, int64_t n, void* stream);
 
 /* ---- sliding-window inference accumulators (reference: tools/Tester.py:107-177, :249-250) --------------------------
  * vmg_tile_accumulate: for a tile `patch` (planes, ph, pw; dtype 0 = f32, 1 = bf16) placed at (oh, ow) of the fp32

@@ -208,6 +208,37 @@ def test_step_tensors_of_the_lockstep_sweeps_fwd_bwd(dtype, n, t):
         assert torch.equal(f.grad[:n], gb[:, t - 1 - j]) and float(f.grad[n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 5, 7), (3, 32, 48)])
+def test_spynet_level_glue_fwd_bwd(dtype, shape):
+    """functional.spy_operand / spy_flow_add (vmg_spy_operand_fwd / _bwd, vmg_spy_flow_add; models/vmg.py:76-85): the level's network input and the
+    flow update, against the torch spelling they replace (cast + cat / float + add) -- bit-exact forward and backward."""
+    from vmg_amd import functional as FH
+    n, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(21)
+    ref = torch.randn((n, h, w, 8), generator=g, device="cuda").to(dtype)
+    warped = torch.randn((n, h, w, 8), generator=g, device="cuda").to(dtype).requires_grad_(True)
+    up = torch.randn((n, h, w, 2), generator=g, device="cuda").requires_grad_(True)
+    got = FH.spy_operand(ref, warped, up)
+    w2, u2 = warped.detach().clone().requires_grad_(True), up.detach().clone().requires_grad_(True)
+    want = torch.cat([ref[..., :3], w2[..., :3], u2.to(dtype)], -1)
+    assert torch.equal(got, want)
+    go = torch.randn(want.shape, generator=g, device="cuda").to(dtype)
+    got.backward(go)
+    want.backward(go)
+    assert torch.equal(warped.grad, w2.grad) and torch.equal(up.grad, u2.grad)
+    res = torch.randn((n, h, w, 2), generator=g, device="cuda").to(dtype).requires_grad_(True)
+    up3 = up.detach().clone().requires_grad_(True)
+    f = FH.spy_flow_add(up3, res)
+    r2, u4 = res.detach().clone().requires_grad_(True), up.detach().clone().requires_grad_(True)
+    fw = u4 + r2.float()
+    assert torch.equal(f, fw)
+    gf = torch.randn(fw.shape, generator=g, device="cuda")
+    f.backward(gf)
+    fw.backward(gf)
+    assert torch.equal(res.grad, r2.grad) and torch.equal(up3.grad, u4.grad)
+
+
 @pytest.mark.parametrize("shape", [(3, 1, 1, 2), (2, 2, 2, 2), (2, 5, 3, 2), (4, 16, 16, 2), (1, 32, 20, 4)])
 def test_flow_upsampling_x2_align_corners_fwd_bwd(shape):
     """SPyNet's flow between pyramid levels (models/vmg.py:97-102): scale * F.interpolate(flow, scale_factor=2, mode='bilinear',

@@ -104,6 +104,46 @@ __global__ void upsample2x_ac_bwd_kernel(const float* __restrict__ src, float* _
   }
 }
 
+// The glue of one pyramid level (models/vmg.py:72-85: `torch.cat([ref[level], warp(supp[level], flow_up), flow_up], 1)` and `flow = flow_up +
+// basic_module(...)`) on the 8-channel pixels this port uses (RGB in channels 0..2, zeros behind): one pass builds the operand
+// [ref RGB | warped RGB | flow] (a 16-byte vector per pixel in bf16), one pass splits its gradient into the warped image's (8 channels, zeros behind
+// the RGB) and the flow's (fp32).  torch spelled it cast + cat forward, two slice-backward zero fills, two copies and a cast backward: 8 launches
+// per level on tensors of a few hundred kB.
+template <typename T>
+struct alignas(8 * sizeof(T) > 16 ? 16 : 8 * sizeof(T)) Px8 { T v[8]; };
+
+template <typename T>
+__global__ void spy_operand_kernel(const Px8<T>* __restrict__ ref, const Px8<T>* __restrict__ warped, const float2* __restrict__ up,
+                                   Px8<T>* __restrict__ out, long long npix) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const Px8<T> r = ref[i], w = warped[i];
+    const float2 f = up[i];
+    Px8<T> o;
+    o.v[0] = r.v[0]; o.v[1] = r.v[1]; o.v[2] = r.v[2];
+    o.v[3] = w.v[0]; o.v[4] = w.v[1]; o.v[5] = w.v[2];
+    o.v[6] = from_f32<T>(f.x); o.v[7] = from_f32<T>(f.y);
+    out[i] = o;
+  }
+}
+
+template <typename T>
+__global__ void spy_operand_bwd_kernel(const Px8<T>* __restrict__ dx8, Px8<T>* __restrict__ dwarped, float2* __restrict__ dup, long long npix) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const Px8<T> d = dx8[i];
+    Px8<T> o;
+    o.v[0] = d.v[3]; o.v[1] = d.v[4]; o.v[2] = d.v[5];
+#pragma unroll
+    for (int e = 3; e < 8; ++e) o.v[e] = from_f32<T>(0.f);
+    dwarped[i] = o;
+    dup[i] = float2{to_f32(d.v[6]), to_f32(d.v[7])};
+  }
+}
+
+template <typename T>
+__global__ void spy_flow_add_kernel(const float* __restrict__ up, const T* __restrict__ res, float* __restrict__ out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = up[i] + to_f32(res[i]);
+}
+
 int blocks_for(long long total) { return (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256)); }
 
 }  // namespace
@@ -132,6 +172,45 @@ extern "C" int vmg_upsample2x_ac_bwd(const float* dy, float* dx, int n, int h, i
   VMG_CHECK(dy && dx && n > 0 && h > 0 && w > 0 && c > 0, "upsample2x_bwd: bad arguments");
   const long long total = (long long)n * h * w * c;
   hipLaunchKernelGGL(upsample2x_ac_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, n, h, w, c, scale);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_spy_operand_fwd(int dtype, const void* ref, const void* warped, const float* up, void* out, int64_t npix, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "spy_operand_fwd: bad dtype");
+  VMG_CHECK(ref && warped && up && out && npix > 0, "spy_operand_fwd: bad arguments");
+  VMG_CHECK(((uintptr_t)ref | (uintptr_t)warped | (uintptr_t)out) % 16 == 0 && (uintptr_t)up % 8 == 0, "spy_operand_fwd: 16-byte aligned 8-channel tensors, 8-byte aligned flow");
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(spy_operand_kernel<bf16>, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, (const Px8<bf16>*)ref, (const Px8<bf16>*)warped,
+                       (const float2*)up, (Px8<bf16>*)out, (long long)npix);
+  else
+    hipLaunchKernelGGL(spy_operand_kernel<float>, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, (const Px8<float>*)ref, (const Px8<float>*)warped,
+                       (const float2*)up, (Px8<float>*)out, (long long)npix);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_spy_operand_bwd(int dtype, const void* dx8, void* dwarped, float* dup, int64_t npix, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "spy_operand_bwd: bad dtype");
+  VMG_CHECK(dx8 && dwarped && dup && npix > 0, "spy_operand_bwd: bad arguments");
+  VMG_CHECK(((uintptr_t)dx8 | (uintptr_t)dwarped) % 16 == 0 && (uintptr_t)dup % 8 == 0, "spy_operand_bwd: 16-byte aligned 8-channel tensors, 8-byte aligned flow gradient");
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(spy_operand_bwd_kernel<bf16>, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, (const Px8<bf16>*)dx8, (Px8<bf16>*)dwarped, (float2*)dup,
+                       (long long)npix);
+  else
+    hipLaunchKernelGGL(spy_operand_bwd_kernel<float>, dim3(blocks_for(npix)), dim3(256), 0, (hipStream_t)stream, (const Px8<float>*)dx8, (Px8<float>*)dwarped, (float2*)dup,
+                       (long long)npix);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_spy_flow_add(int dtype, const float* up, const void* res, float* out, int64_t n, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "spy_flow_add: bad dtype");
+  VMG_CHECK(up && res && out && n > 0, "spy_flow_add: bad arguments");
+  if (dtype == VMG_BF16)
+    hipLaunchKernelGGL(spy_flow_add_kernel<bf16>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, up, (const bf16*)res, out, (long long)n);
+  else
+    hipLaunchKernelGGL(spy_flow_add_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, up, (const float*)res, out, (long long)n);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -1616,6 +1616,39 @@ def upsample2x_flow(x: torch.Tensor, scale: float = 2.0) -> torch.Tensor:
     return _Upsample2xAC.apply(x, float(scale))
 
 
+class _SpyOperand(_Fn):
+    @staticmethod
+    def forward(ctx, ref, warped, up):
+        return K.spy_operand(ref.contiguous(), warped.contiguous(), up.contiguous())
+
+    @staticmethod
+    def backward(ctx, d):
+        dwarped, dup = K.spy_operand_backward(d.contiguous())
+        return None, dwarped, dup
+
+
+def spy_operand(ref: torch.Tensor, warped: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """One pyramid level's network input `cat([ref, warp(supp, flow_up), flow_up])` (models/vmg.py:76-84) as ONE 8-channel tensor [ref RGB | warped RGB |
+    flow] from the 8-channel images (RGB in front) and the fp32 flow; the reference image takes no gradient (the pyramid is built under no_grad)."""
+    return _SpyOperand.apply(ref, warped, up)
+
+
+class _SpyFlowAdd(_Fn):
+    @staticmethod
+    def forward(ctx, up, res):
+        ctx.dt = res.dtype
+        return K.spy_flow_add(up.contiguous(), res.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g.to(ctx.dt)
+
+
+def spy_flow_add(up: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """flow = flow_up + basic_module(...) (models/vmg.py:85): fp32 sum of the fp32 flow and the residual in the compute dtype, one pass."""
+    return _SpyFlowAdd.apply(up, res)
+
+
 def identity_grid(n: int, h: int, w: int, device) -> torch.Tensor:
     ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
     return torch.stack([xs, ys], 0).float()[None].expand(n, -1, -1, -1).contiguous()

@@ -128,6 +128,9 @@ SIGNATURES = {
     "vmg_avgpool2_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_upsample2x_ac_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vmg_upsample2x_ac_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "vmg_spy_operand_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_spy_operand_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_spy_flow_add": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_space_depth_ln_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vmg_space_depth_ln_bwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p]),

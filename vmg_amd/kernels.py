@@ -617,6 +617,40 @@ def avgpool2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def spy_operand(ref: torch.Tensor, warped: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[ref RGB | warped RGB | flow] (n,h,w,8) in ref's dtype from ref, warped (n,h,w,8: RGB in channels 0..2) and up (n,h,w,2) fp32 (vmg_spy_operand_fwd)."""
+    hip.require_cuda(ref, warped, up)
+    if ref.shape[-1] != 8 or warped.shape != ref.shape or warped.dtype != ref.dtype or up.dtype != torch.float32 or tuple(up.shape) != (*ref.shape[:-1], 2) or \
+            not (ref.is_contiguous() and warped.is_contiguous() and up.is_contiguous()):
+        raise HipError("spy_operand: contiguous (..., 8) images of one dtype and a contiguous fp32 (..., 2) flow expected")
+    out = torch.empty_like(ref)
+    hip.check(hip.lib().vmg_spy_operand_fwd(hip.dtype_code(ref.dtype), ref.data_ptr(), warped.data_ptr(), up.data_ptr(), out.data_ptr(), ref.numel() // 8,
+                                            hip.stream_ptr()), "vmg_spy_operand_fwd")
+    return out
+
+
+def spy_operand_backward(dx8: torch.Tensor):
+    """gradient of spy_operand's output -> (d warped (…, 8): channels 3..5 of dx8 in front of zeros, d up (…, 2) fp32: channels 6, 7)."""
+    hip.require_cuda(dx8)
+    if dx8.shape[-1] != 8 or not dx8.is_contiguous():
+        raise HipError("spy_operand_backward: contiguous (..., 8) gradient expected")
+    dwarped = torch.empty_like(dx8)
+    dup = torch.empty((*dx8.shape[:-1], 2), dtype=torch.float32, device=dx8.device)
+    hip.check(hip.lib().vmg_spy_operand_bwd(hip.dtype_code(dx8.dtype), dx8.data_ptr(), dwarped.data_ptr(), dup.data_ptr(), dx8.numel() // 8, hip.stream_ptr()),
+              "vmg_spy_operand_bwd")
+    return dwarped, dup
+
+
+def spy_flow_add(up: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """up (fp32) + res (any compute dtype) -> fp32, one pass (vmg_spy_flow_add)."""
+    hip.require_cuda(up, res)
+    if up.dtype != torch.float32 or up.shape != res.shape or not (up.is_contiguous() and res.is_contiguous()):
+        raise HipError("spy_flow_add: contiguous tensors of one shape, the first fp32")
+    out = torch.empty_like(up)
+    hip.check(hip.lib().vmg_spy_flow_add(hip.dtype_code(res.dtype), up.data_ptr(), res.data_ptr(), out.data_ptr(), up.numel(), hip.stream_ptr()), "vmg_spy_flow_add")
+    return out
+
+
 def upsample2x_ac(x: torch.Tensor, scale: float, backward: bool = False) -> torch.Tensor:
     """forward: (n,h,w,c) fp32 -> scale * bilinear x2 (align_corners=True) (n,2h,2w,c); backward: the transpose on (n,2h,2w,c)."""
     hip.require_cuda(x)

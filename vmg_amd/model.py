@@ -128,9 +128,9 @@ class SPyNet(nn.Module):
             warped = FH.grid_sample_flow(supps[level], up, "bilinear", "border")
             # one 8-channel operand [ref, warped, flow] (a 16-byte vector per pixel) instead of a virtual concat of 3 + 3 + 2 channels:
             # the convolution and its weight gradient then move whole vectors
-            x8 = torch.cat([refs[level][..., :3], warped[..., :3], up.to(dt)], -1)
+            x8 = FH.spy_operand(refs[level], warped, up)
             res = self.basic_module[level]([x8], inner)
-            flow = up + res.float()
+            flow = FH.spy_flow_add(up, res)
         return flow
 
     def forward(self, ref, supp, compute_dtype=torch.float32):
