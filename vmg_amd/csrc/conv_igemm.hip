@@ -1431,14 +1431,23 @@ __global__ __launch_bounds__(WsGeo<NCT>::THREADS, (NCT <= 3 ? 4 : 2)) void conv_
       xf[set][0].load(xb + xo[jj]);
       xf[set][1].load(xb + rowb + xo[jj]);
       const char* wp = ring + slot * STG + jj * KSB + g * (COB * 16) + px * 16;
+#ifdef VMG_WS_ABL_ONE_FRAG
+      wf[set][0].load(wp);  // ablation build (tools/ws_lds_ablate.sh): ONE weight fragment per k-step instead of NCT -- LDS read traffic 11 -> 3 KiB per wave and k-step
+#else
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) wf[set][ct].load(wp + ct * 256);
+#endif
     };
     auto mm = [&](int set) {
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
-        acc[ct][0] = mma(wf[set][ct], xf[set][0], acc[ct][0]);
-        acc[ct][1] = mma(wf[set][ct], xf[set][1], acc[ct][1]);
+#ifdef VMG_WS_ABL_ONE_FRAG
+        constexpr int cw = 0;  // (wrong sums, same MFMA count: is the K loop bound by the LDS reads?)
+#else
+        const int cw = ct;
+#endif
+        acc[ct][0] = mma(wf[set][cw], xf[set][0], acc[ct][0]);
+        acc[ct][1] = mma(wf[set][cw], xf[set][1], acc[ct][1]);
       }
     };
     // one phase = the MFMAs of one k-step with the fragment reads of the next one slotted into the gaps between them (an MFMA
