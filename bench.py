@@ -173,6 +173,22 @@ def psnr_u8(a, b):
     return float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
 
 
+def recorded_roofline(workload):
+    """`roofline` of a run replayed from a hipGraph: HIP events cannot be sampled inside a replayed graph on this ROCm, so the dominant kernel's average launch
+    duration is the rocprofv3 --kernel-trace average of the SAME command run eagerly, recorded in profiles/r04_e_graph_roofline.json (a constant from a
+    committed profile, stated as such -- not a live measurement)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_e_graph_roofline.json")) as f:
+            rec = json.load(f)[workload]
+    except Exception:
+        return None
+    flops = 2.0 * rec["channels"] * rec["channels"] * 9 * rec["pixels"]
+    ach = flops / (rec["avg_launch_us"] * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": rec["kernel"], "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_us": rec["avg_launch_us"], "launches_per_step": rec["launches_per_step"],
+            "measured": "recorded: rocprofv3 --kernel-trace average of the eager run of this command, " + rec["source"] + " (a replayed graph cannot be sampled by events)"}
+
+
 def run_extra(workload, device, steps, warmup, graph):
     """A short timed run of another BASELINE configuration in the same process, AFTER the headline timing (so the driver's default run times
     them too): train_full = the per-GPU shard of configs[2] replayed from a captured hipGraph, infer = configs[3] (one 100-frame sequence per
@@ -212,7 +228,7 @@ def run_extra(workload, device, steps, warmup, graph):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"workload": wl["name"], "value": round(B * Tn * steps / dt, 3), "unit": "LR-frames/s", "ms_per_step": round(dt / steps * 1e3, 2),
-            "steps": steps, "warmup": warmup, "launch": mode}
+            "steps": steps, "warmup": warmup, "launch": mode, "roofline": recorded_roofline(workload) if graph else None}
 
 
 def main():
@@ -424,7 +440,9 @@ def main():
         line["config"]["loss"] = float(loss)
     elif args.graph:
         line["config"]["launch"] = "hipgraph (vmg_amd.infer.GraphedModel: one captured network call, replayed per tile)"
-        line["roofline"] = None
+        line["roofline"] = recorded_roofline("infer") if not args.fp8 else None
+    if train and mode == "hipgraph" and not args.fp8 and args.workload in ("train", "train_full"):
+        line["roofline"] = recorded_roofline(args.workload)
     line["config"]["recompute_chains"] = bool(args.recompute)
     line["config"]["fp8_chains"] = bool(args.fp8)
     line["config"]["peak_device_memory_GB"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
