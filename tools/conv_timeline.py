@@ -1,4 +1,4 @@
-"""In-kernel phase timeline of the k-split conv kernel from s_memrealtime stamps (diagnostics):  conv_timeline.py N tiles"""
+"""In-kernel phase timeline of the k-split conv kernel from s_memrealtime stamps (diagnostics):  conv_timeline.py N tiles [channels]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,13 +8,14 @@ from vmg_amd import hip, kernels as K
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 tiles = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 H = W = 64
-x = torch.randn(N, H, W, 144, device="cuda").to(torch.bfloat16)
-w = torch.randn(144, 144, 3, 3, device="cuda") * 0.03
-b = torch.randn(144, device="cuda")
-res = torch.randn(N, H, W, 144, device="cuda").to(torch.bfloat16)
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 144
+x = torch.randn(N, H, W, C, device="cuda").to(torch.bfloat16)
+w = torch.randn(C, C, 3, 3, device="cuda") * 0.03
+b = torch.randn(C, device="cuda")
+res = torch.randn(N, H, W, C, device="cuda").to(torch.bfloat16)
 out = torch.empty_like(x)
 pw = K.pack_conv_weight(w, torch.bfloat16, cout_tiles=tiles)
-ncb = (144 + tiles * 16 - 1) // (tiles * 16)
+ncb = (C + tiles * 16 - 1) // (tiles * 16)
 nwg = N * 16 * 4 * ncb
 buf = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device="cuda")
 lib = hip.lib()
