@@ -243,6 +243,11 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
  *                    rounding); frames = contiguous blocks of frame_elems elements (whole 16-byte vectors).  The two direction sweeps of
  *                    the recurrence (models/trajectory.py:323-392, 407-477) run as one batch: step j works on [frame t-1-j | frame j] of
  *                    every clip -- that arrangement of the (n, t) features is one gather, its gradient one gather-add.
+ * vmg_sum_n          out = the sum of 2..4 tensors of one dtype (fp32 sum, one rounding): the gradient of a tensor with several consumers -- the hidden
+ *                    state of the recurrence feeds the next step's warp, the attention memory and the output (models/trajectory.py:323-392).
+ * vmg_cast_clear     out = (T)(acc + add) (add optional), acc = 0: the ONE rounding of a finished fp32 scatter accumulator (flow-warp backward,
+ *                    models/trajectory.py:95-116; the key / value frames of the trajectory attention, :672-795) that also leaves the accumulator ready for
+ *                    its next use.  n a multiple of 4.
  * vmg_pair_steps     the same pairing through a POINTER LIST of the t step tensors (2n frames each; the recurrence's step outputs / step
  *                    gradients are separate allocations): mode 0 steps -> a = backward-sweep features, b = forward-sweep features, both (n, t)
  *                    in frame order (trajectory.py:394-395, 479: `feats_.insert(0, ...)` / `append` + stack); mode 1 the inverse (its
@@ -255,6 +260,8 @@ int vmg_linear_wgrad2_multi(int nprob, int npairs, const void* const* x, const v
 int vmg_act_bwd(int dtype, const void* dy, const void* ref, void* out, int64_t n, int act, float slope, float alpha,
                 void* stream);
 int vmg_pixel_shuffle(int dtype, const void* in, void* out, int N, int H, int W, int c, int to_depth, void* stream);
+int vmg_sum_n(int dtype, const void* const* srcs, int nsrc, void* out, int64_t n, void* stream);
+int vmg_cast_clear(int dtype, float* acc, const void* add, void* out, int64_t n, void* stream);
 int vmg_pair_steps(int dtype, int mode, void* const* steps, void* a, void* b, int n, int t, int64_t frame_elems, void* stream);
 int vmg_frame_gather(int dtype, const void* src, void* dst, const int* idx, int64_t frame_elems, int n_src_frames, int n_dst_frames, int nsrc,
                      void* stream);

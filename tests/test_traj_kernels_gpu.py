@@ -169,6 +169,68 @@ def test_pair_frames_is_transpose_flip_cat_and_its_gradient(dtype, n, t):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_fan_out_sums_the_consumers_gradients_in_one_pass(dtype, k):
+    """functional.fan_out (vmg_sum_n, round 4): k handles on one tensor; its gradient is the fp32 sum of the handles' gradients rounded once -- for bf16 at least
+    as close to the exact sum as autograd's pairwise bf16 adds; a handle without a gradient is skipped; no-grad mode hands out the tensor itself."""
+    from vmg_amd import functional as FH
+    g = torch.Generator(device="cuda").manual_seed(41)
+    x = torch.randn((2, 6, 5, 16), generator=g, device="cuda").to(dtype).requires_grad_(True)
+    hs = FH.fan_out(x, k)
+    assert len(hs) == k and all(torch.equal(h, x) for h in hs)
+    gos = [torch.randn(x.shape, generator=g, device="cuda").to(dtype) for _ in range(k)]
+    torch.autograd.backward(list(hs), gos)
+    exact = torch.stack([t.double() for t in gos]).sum(0)
+    if dtype == torch.float32:
+        assert torch.allclose(x.grad.double(), exact, rtol=0, atol=1e-5)
+    else:
+        pair = gos[0]
+        for t in gos[1:]:
+            pair = pair + t
+        assert float((x.grad.double() - exact).abs().max()) <= float((pair.double() - exact).abs().max()) + 1e-12
+        assert torch.equal(x.grad, exact.float().to(dtype)) or float((x.grad.float() - exact.float().to(dtype).float()).abs().max()) <= 2 ** -8 * float(exact.abs().max())
+    x.grad = None
+    hs = FH.fan_out(x, 3)
+    (hs[0] * 2).sum().backward()  # two handles unused
+    assert torch.equal(x.grad, torch.full_like(x, 2.0))
+    with torch.no_grad():
+        assert all(h is x for h in FH.fan_out(x, 3))
+
+
+def test_scatter_accumulators_are_rounded_once_and_left_zero():
+    """kernels.cast_clear (vmg_cast_clear) and the accumulator pool (round 4): the fp32 sums of the flow-warp backward and of the attention's gradient banks are
+    rounded by one pass that also clears the buffer, so the next scatter needs no fill.  The rounding equals torch's; a pooled buffer is all zero at rest,
+    whatever ran before; two backward calls in a row give the same bits as with fresh zero-filled accumulators."""
+    from vmg_amd import functional as FH, kernels as K
+    g = torch.Generator(device="cuda").manual_seed(31)
+    acc = torch.randn((3, 5, 7, 16), generator=g, device="cuda")
+    add = torch.randn((3, 5, 7, 16), generator=g, device="cuda").to(torch.bfloat16)
+    want = (acc + add.float()).to(torch.bfloat16)
+    want0 = acc.to(torch.bfloat16)
+    a1, a2 = acc.clone(), acc.clone()
+    assert torch.equal(K.cast_clear(a1, torch.bfloat16, add=add), want) and float(a1.abs().max()) == 0.0
+    assert torch.equal(K.cast_clear(a2, torch.bfloat16), want0) and float(a2.abs().max()) == 0.0
+    K.ACC_POOL.clear()
+    x = torch.randn((2, 16, 16, 32), generator=g, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    flow = (4.0 * torch.randn((2, 16, 16, 2), generator=g, device="cuda")).requires_grad_(True)
+    go = torch.randn((2, 16, 16, 32), generator=g, device="cuda").to(torch.bfloat16)
+    grads = []
+    for _ in range(3):
+        x.grad = flow.grad = None
+        FH.grid_sample_flow(x, flow, "bilinear", "border").backward(go)
+        grads.append((x.grad.clone(), flow.grad.clone()))
+        pooled = K.ACC_POOL.free[((2, 16, 16, 32), str(x.device))]
+        assert len(pooled) == 1 and float(pooled[0].abs().max()) == 0.0
+    K.ACC_POOL.clear()
+    x.grad = flow.grad = None
+    FH.grid_sample_flow(x, flow, "bilinear", "border").backward(go)  # a fresh accumulator
+    for gx, gf in grads:
+        # (float atomics: the arrival order may differ between launches by the last bits of the fp32 sum -- at most one bf16 ulp after the rounding)
+        assert float((gx.float() - x.grad.float()).abs().max()) <= 2 ** -7 * float(x.grad.float().abs().max())
+        assert torch.allclose(gf, flow.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n,t", [(1, 1), (2, 5), (4, 7)])
 def test_step_tensors_of_the_lockstep_sweeps_fwd_bwd(dtype, n, t):
     """functional.pair_frame_steps / unpair_steps (vmg_pair_steps, round 4): the recurrence's per-step tensors as separate allocations.

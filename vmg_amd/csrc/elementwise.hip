@@ -538,6 +538,53 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const T* __restrict__
     }
   }
 }
+// out = sum of 2..4 tensors of one dtype, fp32 sum, one rounding: the gradient of a tensor with several consumers (functional.fan_out) in ONE pass -- autograd
+// sums them pairwise (k - 1 passes of 3 tensors each, a rounding per pass).
+struct SumNK { const void* src[4]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumNK k, T* __restrict__ out, long long nv) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  typedef VecN<T, VN> Vec;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    float acc[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < k.n) {  // (wave-uniform)
+        const Vec a = reinterpret_cast<const Vec*>(k.src[j])[i];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] += to_f32(a.v[e]);
+      }
+    }
+    Vec o;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o.v[e] = from_f32<T>(acc[e]);
+    reinterpret_cast<Vec*>(out)[i] = o;
+  }
+}
+
+// fp32 scatter accumulators (flow-warp backward, the trajectory attention's key / value gradient banks) are rounded to the tensor dtype ONCE, when complete.
+// This pass does the rounding, adds an optional further gradient (`add`: the frame's other uses, fp32 sum before the rounding) and leaves the accumulator
+// ZERO behind -- so that the host can hand the same buffer to the next scatter without a fill pass (round 4: 25 fills + 25 casts + 8 adds per train step
+// were torch kernels).
+template <typename T>
+__global__ __launch_bounds__(256) void cast_clear_kernel(float* __restrict__ acc, const T* __restrict__ add, T* __restrict__ out, long long n4) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(acc)[i];
+    if (add) {
+      const VecN<T, 4> a = reinterpret_cast<const VecN<T, 4>*>(add)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += to_f32(a.v[e]);
+    }
+    VecN<T, 4> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = from_f32<T>(v[e]);
+    reinterpret_cast<VecN<T, 4>*>(out)[i] = o;
+    reinterpret_cast<f32x4*>(acc)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // The step tensors of the lock-step recurrence, addressed through a POINTER LIST (the t step tensors are separate allocations: the residual chain
 // of step j writes its own output).  Step j holds 2n frames: rows [0, n) = the backward sweep at frame t-1-j, rows [n, 2n) = the forward sweep at
 // frame j of every clip.
@@ -616,6 +663,37 @@ extern "C" int vmg_frame_gather(int dtype, const void* src, void* dst, const int
   if (dtype == VMG_BF16) { if (nsrc == 1) FG_LAUNCH(bf16, 1); else FG_LAUNCH(bf16, 2); }
   else { if (nsrc == 1) FG_LAUNCH(float, 1); else FG_LAUNCH(float, 2); }
 #undef FG_LAUNCH
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_sum_n(int dtype, const void* const* srcs, int nsrc, void* out, int64_t n, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "sum_n: bad dtype");
+  const int vn = dtype == VMG_BF16 ? 8 : 4;
+  VMG_CHECK(srcs && out && nsrc >= 2 && nsrc <= 4 && n > 0 && n % vn == 0 && (uintptr_t)out % 16 == 0, "sum_n: 2..4 sources, whole 16-byte vectors, aligned tensors");
+  SumNK k;
+  k.n = nsrc;
+  for (int j = 0; j < 4; ++j) {
+    k.src[j] = j < nsrc ? srcs[j] : nullptr;
+    VMG_CHECK(j >= nsrc || (srcs[j] && (uintptr_t)srcs[j] % 16 == 0), "sum_n: source %d null or unaligned", j);
+  }
+  const long long nv = n / vn;
+  const int blocks = (int)(cdiv64(nv, 256) > 4096 ? 4096 : cdiv64(nv, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(sum_n_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k, (bf16*)out, nv);
+  else hipLaunchKernelGGL(sum_n_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k, (float*)out, nv);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_cast_clear(int dtype, float* acc, const void* add, void* out, int64_t n, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "cast_clear: bad dtype");
+  VMG_CHECK(acc && out && n > 0 && n % 4 == 0, "cast_clear: n must be a positive multiple of 4");
+  VMG_CHECK((uintptr_t)acc % 16 == 0 && (uintptr_t)out % 8 == 0 && (uintptr_t)add % 8 == 0, "cast_clear: 16-byte aligned accumulator, 8-byte aligned tensors");
+  VMG_CHECK(dtype == VMG_BF16 || ((uintptr_t)out % 16 == 0 && (uintptr_t)add % 16 == 0), "cast_clear: 16-byte aligned fp32 tensors");
+  const long long n4 = n / 4;
+  const int blocks = (int)(cdiv64(n4, 256) > 4096 ? 4096 : cdiv64(n4, 256));
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(cast_clear_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (const bf16*)add, (bf16*)out, n4);
+  else hipLaunchKernelGGL(cast_clear_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (const float*)add, (float*)out, n4);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -1671,8 +1671,7 @@ class _WarpBilinear(_Fn):
     @staticmethod
     def backward(ctx, dy):
         x, flow = ctx.saved_tensors
-        dx_acc, dflow = K.warp_bilinear_backward(x, flow, dy)
-        return dx_acc.to(x.dtype), dflow
+        return K.warp_bilinear_backward(x, flow, dy)
 
 
 def grid_sample_flow(x: torch.Tensor, flow: torch.Tensor, mode: str, padding: str) -> torch.Tensor:
@@ -1687,6 +1686,37 @@ def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
     """Advect the tracked-location maps (n,2k,h,w) with nearest sampling, border padding (trajectory.py:332-333).
     Not differentiable (the reference's nearest sampling has zero gradient w.r.t. grid and the maps are constants)."""
     return K.warp_nearest_planes(loc.detach(), flow.detach().contiguous())
+
+
+class _FanOut(_Fn):
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        g0 = gs[0]
+        vn = 8 if g0.dtype == torch.bfloat16 else 4
+        if len(gs) <= 4 and g0.dtype in (torch.bfloat16, torch.float32) and g0.numel() % vn == 0 and all(g.dtype == g0.dtype and g.shape == g0.shape for g in gs):
+            return K.sum_n([g.contiguous() for g in gs]), None
+        tot = gs[0]
+        for g in gs[1:]:
+            tot = tot + g
+        return tot, None
+
+
+def fan_out(x: torch.Tensor, k: int):
+    """k handles on x, one per consumer: the gradient of x is then ONE sum over the consumers' gradients (fp32, one rounding, vmg_sum_n) instead of autograd's
+    k - 1 pairwise adds.  Without gradients: x itself, k times."""
+    if k == 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * k
+    return _FanOut.apply(x, k)
 
 
 class _GradBank:
@@ -1715,9 +1745,15 @@ class _Banked(_Fn):
         buf, ctx.bank.buf = ctx.bank.buf, None
         if buf is None:
             return g, None
+        dt = ctx.bank.dtype
+        if dt != torch.float32 and buf.numel() % 4 == 0 and (g is None or g.dtype == dt):
+            # ONE rounding of the finished sum (+ the gradient of the frame's other uses, added in fp32), and the accumulator goes back to the pool cleared
+            out = K.cast_clear(buf, dt, add=g.contiguous() if g is not None else None)
+            K.ACC_POOL.give(buf)
+            return out, None
         if g is not None:
             buf.add_(g)  # (fp32 += the gradient of the frame's other uses)
-        return buf.to(ctx.bank.dtype), None  # ONE rounding of the finished sum
+        return buf.to(dt), None
 
 
 def grad_bank(x: torch.Tensor) -> torch.Tensor:
@@ -1759,7 +1795,7 @@ class _LTAM(_Fn):
                 into.append(None)
                 continue
             if b.buf is None:
-                b.buf = torch.zeros_like(q, dtype=torch.float32)
+                b.buf = K.ACC_POOL.take(q.shape, q.device) if q.dtype != torch.float32 else torch.zeros_like(q, dtype=torch.float32)
             into.append(b.buf)
         dq, dk, dv, drpe = K.ltam_backward(q, keys, vals, loc, rpe, decay_v, out, lse, dout, heads, wh, ww, scale, dk_into=into[:t], dv_into=into[t:])
         # banked frames: their _Banked node hands the sum on; the others: fp32 sums rounded to the tensors' dtype here, once

@@ -87,6 +87,8 @@ SIGNATURES = {
     "vmg_resblock_chain_bwd": (c_int, [POINTER(ChainDesc), c_void_p]),
     "vmg_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_void_p]),
     "vmg_pixel_shuffle": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_sum_n": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "vmg_cast_clear": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_pair_steps": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "vmg_frame_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "vmg_pixel_unshuffle_actgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),

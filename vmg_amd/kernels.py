@@ -369,6 +369,51 @@ def frame_gather(src: torch.Tensor, idx: torch.Tensor, n_dst: int, frame_shape) 
     return dst
 
 
+def sum_n(ts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Sum of 2..4 contiguous tensors of one shape and dtype (bf16 / fp32), fp32 sum, one rounding (vmg_sum_n)."""
+    hip.require_cuda(*ts)
+    t0 = ts[0]
+    vn = 8 if t0.dtype == torch.bfloat16 else 4
+    if not 2 <= len(ts) <= 4 or t0.numel() % vn or any(t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous() for t in ts):
+        raise HipError("sum_n: 2..4 contiguous tensors of one shape and dtype, whole 16-byte vectors")
+    out = torch.empty_like(t0)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    hip.check(hip.lib().vmg_sum_n(hip.dtype_code(t0.dtype), ptrs, len(ts), out.data_ptr(), t0.numel(), hip.stream_ptr()), "vmg_sum_n")
+    return out
+
+
+class _AccPool:
+    """fp32 scatter accumulators at rest are ZERO (cast_clear leaves them so): a buffer is taken for one scatter, rounded + cleared, given back -- no fill pass per
+    use.  A buffer that is not given back (an exception in between) is simply dropped.  One stream: every user runs on the current stream, in order."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, shape, device) -> torch.Tensor:
+        lst = self.free.get((tuple(shape), str(device)))
+        return lst.pop() if lst else torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+
+    def give(self, buf: torch.Tensor) -> None:
+        self.free.setdefault((tuple(buf.shape), str(buf.device)), []).append(buf)
+
+    def clear(self) -> None:
+        self.free.clear()
+
+
+ACC_POOL = _AccPool()
+
+
+def cast_clear(acc: torch.Tensor, dtype: torch.dtype, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(acc [+ add]) rounded to `dtype` once; acc (contiguous fp32) is ZERO afterwards (vmg_cast_clear)."""
+    hip.require_cuda(acc, add)
+    if acc.dtype != torch.float32 or not acc.is_contiguous() or acc.numel() % 4 or (add is not None and (add.dtype != dtype or add.shape != acc.shape or not add.is_contiguous())):
+        raise HipError("cast_clear: contiguous fp32 accumulator (a multiple of 4 elements); `add` of the output dtype and the same shape")
+    out = torch.empty(acc.shape, dtype=dtype, device=acc.device)
+    hip.check(hip.lib().vmg_cast_clear(hip.dtype_code(dtype), acc.data_ptr(), add.data_ptr() if add is not None else None, out.data_ptr(), acc.numel(), hip.stream_ptr()),
+              "vmg_cast_clear")
+    return out
+
+
 def pair_steps(mode: int, steps: Sequence[torch.Tensor], a: torch.Tensor, b: Optional[torch.Tensor], n: int, t: int) -> None:
     """vmg_pair_steps: the t step tensors of the lock-step recurrence ((2n, *frame) each, separate allocations) <-> a, b = the two sweeps' features
     (n, t, *frame) in frame order.  mode 0: steps -> a, b; mode 1: a, b -> steps; mode 2: a[i, f] = steps[t-1-f][i] + steps[f][n+i] (b unused)."""
@@ -846,13 +891,20 @@ def warp_bilinear_forward(x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
 
 
 def warp_bilinear_backward(x: torch.Tensor, flow: torch.Tensor, dy: torch.Tensor):
+    """-> (dx in x's dtype, dflow fp32)."""
     n, h, w, c = x.shape
     dy = dy.contiguous()
-    dx_acc = torch.zeros((n, h, w, c), dtype=torch.float32, device=x.device)  # fp32 sums for bf16 tensors too: rounded once by the caller
+    # fp32 sums for bf16 tensors too, rounded once: the accumulator comes from the pool of zeroed buffers and goes back cleared by the rounding pass
+    pooled = x.dtype != torch.float32 and (n * h * w * c) % 4 == 0
+    dx_acc = ACC_POOL.take((n, h, w, c), x.device) if pooled else torch.zeros((n, h, w, c), dtype=torch.float32, device=x.device)
     dflow = torch.empty((n, h, w, 2), dtype=torch.float32, device=x.device)  # every element is written
     hip.check(hip.lib().vmg_warp_bilinear_bwd(hip.dtype_code(x.dtype), x.data_ptr(), flow.data_ptr(), dy.data_ptr(), dx_acc.data_ptr(),
                                               dflow.data_ptr(), n, h, w, c, hip.stream_ptr()), "vmg_warp_bilinear_bwd")
-    return dx_acc, dflow
+    if pooled:
+        dx = cast_clear(dx_acc, x.dtype)
+        ACC_POOL.give(dx_acc)
+        return dx, dflow
+    return dx_acc.to(x.dtype), dflow
 
 
 def warp_nearest_planes(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:

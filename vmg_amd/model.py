@@ -388,7 +388,8 @@ class Trajectory_multi_head(nn.Module):
         fb = flows_backward.permute(1, 0, 3, 4, 2).float()
         ff = flows_forward.permute(1, 0, 3, 4, 2).float()
         s = self.keyframe_stride
-        curs = FH.pair_frame_steps(x)  # t tensors (2n, h, w, c): step j -> [frame t-1-j | frame j], one gather from the batch-major features
+        x_steps, x = FH.fan_out(x, 2)  # (the features feed the recurrence AND the fusion conv below)
+        curs = FH.pair_frame_steps(x_steps)  # t tensors (2n, h, w, c): step j -> [frame t-1-j | frame j], one gather from the batch-major features
         # step j >= 1 warps by flows_backward[:, t-1-j] (backward sweep) and flows_forward[:, j-1] (forward sweep)
         flpair = torch.cat([fb.flip(0), ff], 1).contiguous() if t > 1 else None  # (t-1, 2n, h, w, 2); row j-1 serves step j
         ident = FH.identity_grid(2 * n, h, w, x.device)
@@ -401,21 +402,30 @@ class Trajectory_multi_head(nn.Module):
         # backward of unbind is one stack.  The features' step tensors come from / go to one kernel each way: pair_frame_steps, unpair_steps.)
         fls = flpair.unbind(0) if flpair is not None else ()
         for j in range(t):
-            cur = curs[j]
+            key, last = j % s == 0, j == t - 1
+            # a step's input frame feeds the attention (as its query), the residual chain and -- on a key frame -- the attention memory; the hidden state feeds
+            # the output, the next step's warp and the memory: one handle per consumer (FH.fan_out), so that the gradient is ONE sum, not autograd's pairwise adds
+            hd = list(FH.fan_out(curs[j], (1 if j > 0 else 0) + 1 + (1 if key else 0)))
+            cur_q = hd.pop() if j > 0 else None
+            cur_c = hd.pop()
+            cur_k = hd.pop() if key else None
             if j == 0:
-                feat = torch.zeros_like(cur)
+                feat = torch.zeros_like(cur_c)
             else:
                 fl = fls[j - 1]
-                feat = flow_warp_nhwc(feat, fl, "bilinear", "border")
+                feat = flow_warp_nhwc(feat_next, fl, "bilinear", "border")
                 loc = FH.warp_locations(loc, fl)
-                feat = self.LTAM(cur, k_in, feat, k_state, loc)
-                if j % s == 0:
+                feat = self.LTAM(cur_q, k_in, feat, k_state, loc)
+                if key:
                     loc = torch.cat([loc, ident], 1)
-            feat = self.resblocks([cur, feat])
-            if j % s == 0:  # (grad_bank: the later frames' attention backward calls sum their gradients w.r.t. this key-frame in one buffer)
-                k_state.append(FH.grad_bank(feat))
-                k_in.append(FH.grad_bank(cur))
-            feats.append(feat)
+            feat = self.resblocks([cur_c, feat])
+            hd = list(FH.fan_out(feat, 1 + (0 if last else 1) + (1 if key else 0)))
+            f_out = hd.pop()
+            feat_next = None if last else hd.pop()
+            if key:  # (grad_bank: the later frames' attention backward calls sum their gradients w.r.t. this key-frame in one buffer)
+                k_state.append(FH.grad_bank(hd.pop()))
+                k_in.append(FH.grad_bank(cur_k))
+            feats.append(f_out)
         # step j: (backward sweep at frame t-1-j, forward sweep at frame j) -> both sweeps (n, t, h, w, c) in frame order.  The fusion is a 1x1 conv:
         # its pixels may come in any order -- batch-major like x, so neither x nor the result is transposed
         back, fwd = FH.unpair_steps(feats, n)
