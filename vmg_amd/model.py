@@ -747,22 +747,23 @@ class VMG(nn.Module):
 
     def forward_features_multi_stages(self, x, ff, fb):
         enc, dec, down, up = self.encoder_layers, self.decoder_layers, self.downsample, self.upsample
-        x1 = enc[0](x, ff[0], fb[0])
-        x1_3 = self._mdsc(self.sc_64_16, x1) if self.mdsc else 0
-        x2 = enc[1](down[0](x1), ff[1], fb[1])
-        x2_4 = self._mdsc(self.sc_32_8, x2) if self.mdsc else 0
-        x3 = enc[2](down[1](x2), ff[2], fb[2])
+        # (a stage output with several consumers -- next stage, long skip, multi-scale skip -- goes out as one handle per consumer: FH.fan_out)
+        x1, x1_skip, x1_ms = FH.fan_out(enc[0](x, ff[0], fb[0]), 3)
+        x1_3 = self._mdsc(self.sc_64_16, x1_ms) if self.mdsc else 0
+        x2, x2_skip, x2_ms = FH.fan_out(enc[1](down[0](x1), ff[1], fb[1]), 3)
+        x2_4 = self._mdsc(self.sc_32_8, x2_ms) if self.mdsc else 0
+        x3, x3_skip = FH.fan_out(enc[2](down[1](x2), ff[2], fb[2]), 2)
         x4 = enc[3](down[2](x3 + x1_3), ff[3], fb[3])
         x5 = dec[0](up[0](x4 + x2_4), ff[2], fb[2])
-        x6 = dec[1](up[1](x5 + x3), ff[1], fb[1])
-        x7 = dec[2](up[2](x6 + x2), ff[0], fb[0])
-        return x7 + x1
+        x6 = dec[1](up[1](x5 + x3_skip), ff[1], fb[1])
+        x7 = dec[2](up[2](x6 + x2_skip), ff[0], fb[0])
+        return x7 + x1_skip
 
     def forward_features_few_stages(self, x, ff, fb):
-        x1 = self.encoder_layers[0](x, ff[0], fb[0])
+        x1, x1_skip = FH.fan_out(self.encoder_layers[0](x, ff[0], fb[0]), 2)
         x2 = self.encoder_layers[1](self.downsample[0](x1), ff[1], fb[1])
         x3 = self.decoder_layers[0](self.upsample[0](x2), ff[0], fb[0])
-        return x3 + x1
+        return x3 + x1_skip
 
     def reconstruct(self, y, N, H, W):
         """The 4x head on channels-last features (N,H,W,C) -> (N,4H,4W,3): upconv1 / PixelShuffle / lrelu, upconv2 / PixelShuffle / lrelu,
