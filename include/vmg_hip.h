@@ -327,6 +327,10 @@ int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out
 int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow, const void* dy, void* dx_acc, float* dflow, int N, int H,
                           int W, int C, void* stream);
 int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int N, int K2, int H, int W, void* stream);
+/* vmg_flow_smooth: the flow smoothing in front of a trajectory stage (models/function.py:1466-1478: reflect-pad right / bottom to a multiple of r, r x r mean,
+ * nearest x r, crop) on `planes` fp32 planes of H x W; backward = 0: out = smoothed planes, backward = 1: `in` is the output gradient, `out` the input gradient
+ * (a gather: deterministic, no zero-fill).  The padding must be smaller than the plane, as F.pad(mode='reflect') demands. */
+int vmg_flow_smooth(const float* in, float* out, int64_t planes, int H, int W, int r, int backward, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Trajectory window attention = LTAM_multi_head.forward_wins without the output projection
@@ -439,6 +443,9 @@ int vmg_upsample2x_ac_bwd(const float* dy, float* dx, int n, int h, int w, int c
 int vmg_spy_operand_fwd(int dtype, const void* ref, const void* warped, const float* up, void* out, int64_t npix, void* stream);
 int vmg_spy_operand_bwd(int dtype, const void* dx8, void* dwarped, float* dup, int64_t npix, void* stream);
 int vmg_spy_flow_add(int dtype, const float* up, const void* res, float* out, int64_t n, void* stream);
+/* vmg_spy_prep: SPyNet's input normalisation (models/vmg.py:104-106): img (n, 3, h, w) fp32, mean / std (3) fp32 on the device -> out (n, h, w, 8) in `dtype`,
+ * channels 0..2 = (img - mean) / std, zeros behind. */
+int vmg_spy_prep(int dtype, const float* img, const float* mean, const float* stdv, void* out, int64_t n, int h, int w, void* stream);
 
 /* ---- sliding-window inference accumulators (reference: tools/Tester.py:107-177, :249-250) --------------------------
  * vmg_tile_accumulate: for a tile `patch` (planes, ph, pw; dtype 0 = f32, 1 = bf16) placed at (oh, ow) of the fp32

@@ -197,6 +197,29 @@ def test_fan_out_sums_the_consumers_gradients_in_one_pass(dtype, k):
         assert all(h is x for h in FH.fan_out(x, 3))
 
 
+@pytest.mark.parametrize("shape,r", [((2, 3, 2, 30, 26), 4), ((1, 2, 2, 64, 64), 4), ((1, 1, 2, 9, 7), 4), ((2, 1, 2, 5, 5), 3), ((1, 1, 2, 8, 8), 1)])
+def test_flow_smoothing_kernel_fwd_bwd(shape, r):
+    """functional.flow_smooth (vmg_flow_smooth, round 4) against the torch spelling it replaces -- F.pad(reflect) + adaptive_avg_pool2d + nearest x r + crop
+    (models/function.py:1466-1478) -- forward and gradient, sizes with and without padding on either axis."""
+    import numpy as np
+    import torch.nn.functional as F
+    from vmg_amd import functional as FH
+    g = torch.Generator(device="cuda").manual_seed(51)
+    flow = torch.randn(shape, generator=g, device="cuda").requires_grad_(True)
+    got = FH.flow_smooth(flow, r)
+    fr = flow.detach().clone().requires_grad_(True)
+    B, T, C, H, W = shape
+    hf, wf = int(np.ceil(H / r)) * r, int(np.ceil(W / r)) * r
+    f = F.pad(fr.reshape(-1, C, H, W), (0, wf - W, 0, hf - H), mode="reflect")
+    f = F.adaptive_avg_pool2d(f, (hf // r, wf // r))
+    want = F.interpolate(f, scale_factor=r, mode="nearest")[..., :H, :W].reshape(shape)
+    assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    go = torch.randn(shape, generator=g, device="cuda")
+    got.backward(go)
+    want.backward(go)
+    assert torch.allclose(flow.grad, fr.grad, rtol=1e-5, atol=1e-6)
+
+
 def test_scatter_accumulators_are_rounded_once_and_left_zero():
     """kernels.cast_clear (vmg_cast_clear) and the accumulator pool (round 4): the fp32 sums of the flow-warp backward and of the attention's gradient banks are
     rounded by one pass that also clears the buffer, so the next scatter needs no fill.  The rounding equals torch's; a pooled buffer is all zero at rest,

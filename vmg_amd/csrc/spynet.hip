@@ -144,6 +144,25 @@ __global__ void spy_flow_add_kernel(const float* __restrict__ up, const T* __res
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = up[i] + to_f32(res[i]);
 }
 
+// SPyNet's input normalisation (models/vmg.py:104-106 `(x - mean) / std`) written straight into this port's pixel layout: (n, 3, h, w) fp32 -> (n, h, w, 8) T with zeros
+// behind the RGB -- torch spelled it sub, div, permute + pad, cast: four launches per image batch.
+template <typename T>
+__global__ void spy_prep_kernel(const float* __restrict__ img, const float* __restrict__ mean, const float* __restrict__ stdv, Px8<T>* __restrict__ out, long long n, int hw) {
+  const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n * hw; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw;
+    const int p = (int)(i - b * hw);
+    const float* src = img + b * 3 * hw + p;
+    Px8<T> o;
+    o.v[0] = from_f32<T>(__fdiv_rn(__fsub_rn(src[0], m0), s0));
+    o.v[1] = from_f32<T>(__fdiv_rn(__fsub_rn(src[hw], m1), s1));
+    o.v[2] = from_f32<T>(__fdiv_rn(__fsub_rn(src[2 * hw], m2), s2));
+#pragma unroll
+    for (int e = 3; e < 8; ++e) o.v[e] = from_f32<T>(0.f);
+    out[i] = o;
+  }
+}
+
 int blocks_for(long long total) { return (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256)); }
 
 }  // namespace
@@ -211,6 +230,16 @@ extern "C" int vmg_spy_flow_add(int dtype, const float* up, const void* res, flo
     hipLaunchKernelGGL(spy_flow_add_kernel<bf16>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, up, (const bf16*)res, out, (long long)n);
   else
     hipLaunchKernelGGL(spy_flow_add_kernel<float>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, up, (const float*)res, out, (long long)n);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_spy_prep(int dtype, const float* img, const float* mean, const float* stdv, void* out, int64_t n, int h, int w, void* stream) {
+  VMG_CHECK(dtype == VMG_F32 || dtype == VMG_BF16, "spy_prep: bad dtype");
+  VMG_CHECK(img && mean && stdv && out && n > 0 && h > 0 && w > 0 && (uintptr_t)out % 16 == 0, "spy_prep: bad arguments");
+  const long long total = (long long)n * h * w;
+  if (dtype == VMG_BF16) hipLaunchKernelGGL(spy_prep_kernel<bf16>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, img, mean, stdv, (Px8<bf16>*)out, (long long)n, h * w);
+  else hipLaunchKernelGGL(spy_prep_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, img, mean, stdv, (Px8<float>*)out, (long long)n, h * w);
   VMG_LAUNCH_CHECK();
   return 0;
 }

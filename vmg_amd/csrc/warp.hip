@@ -181,6 +181,54 @@ int grid_for(long long total) {
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+// ------------------------------------------------------------------------------------------ flow smoothing (models/function.py:1466-1478)
+// reflect-pad the (n, c, H, W) flow planes on the right / bottom to a multiple of r, r x r mean, nearest x r, crop: out[y][x] = the mean of the padded plane over
+// the r x r block that holds (y, x).  One thread per element, the block read directly through the reflection (the planes are a few hundred kB); the backward is the
+// adjoint as a GATHER (an input pixel is its own padded position and at most one mirror image per axis): no atomics, no zero-fill.  torch spelled it pad + adaptive
+// average pool + expand / reshape / crop copy: 3 launches forward and 4 backward per call on tiny tensors.
+__device__ __forceinline__ int fs_reflect(int p, int n) { return p < n ? p : 2 * (n - 1) - p; }
+
+__global__ void flow_smooth_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int H, int W, int r) {
+  const long long total = planes * H * W;
+  const float inv = 1.0f / (float)(r * r);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float* pl = in + (i / ((long long)W * H)) * H * W;
+    const int y0 = (y / r) * r, x0 = (x / r) * r;
+    float s = 0.f;
+    for (int dy = 0; dy < r; ++dy) {
+      const float* row = pl + (long long)fs_reflect(y0 + dy, H) * W;
+      for (int dx = 0; dx < r; ++dx) s += row[fs_reflect(x0 + dx, W)];
+    }
+    out[i] = s * inv;
+  }
+}
+
+__global__ void flow_smooth_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long long planes, int H, int W, int r) {
+  const long long total = planes * H * W;
+  const int hf = (H + r - 1) / r * r, wf = (W + r - 1) / r * r;
+  const float inv = 1.0f / (float)(r * r);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float* pl = dout + (i / ((long long)W * H)) * H * W;
+    // padded positions that read input (y, x): itself and its mirror image 2 (n - 1) - p when that lies in the padding [n, nf)
+    int py[2] = {y, 2 * (H - 1) - y}, px[2] = {x, 2 * (W - 1) - x};
+    const int ny = (py[1] >= H && py[1] < hf) ? 2 : 1, nx = (px[1] >= W && px[1] < wf) ? 2 : 1;
+    float acc = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      const int y0 = (py[a] / r) * r;
+      for (int b = 0; b < nx; ++b) {
+        const int x0 = (px[b] / r) * r;
+        float g = 0.f;  // sum of the output gradients of the block (its cropped part)
+        for (int dy = 0; dy < r && y0 + dy < H; ++dy)
+          for (int dx = 0; dx < r && x0 + dx < W; ++dx) g += pl[(long long)(y0 + dy) * W + x0 + dx];
+        acc += g;
+      }
+    }
+    din[i] = acc * inv;
+  }
+}
+
 }  // namespace
 
 extern "C" int vmg_warp_bilinear_fwd(int dtype, const void* x, const float* flow, void* out, int N, int H, int W, int C, void* stream) {
@@ -218,6 +266,17 @@ extern "C" int vmg_warp_bilinear_bwd(int dtype, const void* x, const float* flow
 extern "C" int vmg_warp_nearest_planes(const float* loc, const float* flow, float* out, int N, int K2, int H, int W, void* stream) {
   VMG_CHECK(loc && flow && out && N > 0 && K2 > 0 && H > 0 && W > 0, "warp_nearest: bad arguments");
   hipLaunchKernelGGL(warp_nearest_planes_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, loc, flow, out, N, K2, H, W);
+  VMG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmg_flow_smooth(const float* in, float* out, int64_t planes, int H, int W, int r, int backward, void* stream) {
+  VMG_CHECK(in && out && planes > 0 && H > 0 && W > 0 && r >= 1, "flow_smooth: bad arguments");
+  const int hf = (H + r - 1) / r * r, wf = (W + r - 1) / r * r;
+  VMG_CHECK(hf - H < H && wf - W < W, "flow_smooth: the reflected padding must be smaller than the plane (as F.pad(mode='reflect') demands)");
+  const long long total = planes * H * W;
+  if (backward) hipLaunchKernelGGL(flow_smooth_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)planes, H, W, r);
+  else hipLaunchKernelGGL(flow_smooth_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)planes, H, W, r);
   VMG_LAUNCH_CHECK();
   return 0;
 }

@@ -1682,6 +1682,23 @@ def grid_sample_flow(x: torch.Tensor, flow: torch.Tensor, mode: str, padding: st
     return _WarpBilinear.apply(x, flow.float())
 
 
+class _FlowSmooth(_Fn):
+    @staticmethod
+    def forward(ctx, flow, r):
+        ctx.r = r
+        return K.flow_smooth(flow.contiguous(), r)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.flow_smooth(g.contiguous(), ctx.r, backward=True), None
+
+
+def flow_smooth(flow: torch.Tensor, r: int) -> torch.Tensor:
+    """Mlp_encoder's flow smoothing (models/function.py:1466-1478): reflect-pad to a multiple of r, r x r mean, nearest x r, crop -- one kernel each way on the
+    (..., H, W) fp32 flow planes."""
+    return _FlowSmooth.apply(flow.float(), int(r))
+
+
 def warp_locations(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
     """Advect the tracked-location maps (n,2k,h,w) with nearest sampling, border padding (trajectory.py:332-333).
     Not differentiable (the reference's nearest sampling has zero gradient w.r.t. grid and the maps are constants)."""

@@ -133,6 +133,7 @@ SIGNATURES = {
     "vmg_spy_operand_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_spy_operand_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vmg_spy_flow_add": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vmg_spy_prep": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vmg_space_depth_ln_fwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vmg_space_depth_ln_bwd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p]),
@@ -141,6 +142,7 @@ SIGNATURES = {
     "vmg_warp_bilinear_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_warp_bilinear_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_warp_nearest_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vmg_flow_smooth": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vmg_ltam_fwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vmg_ltam_bwd": (c_int, [c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -662,6 +662,19 @@ def avgpool2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def spy_prep(img: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """img (n,3,h,w) fp32 contiguous -> (n,h,w,8) `dtype`: (img - mean) / std in channels 0..2, zeros behind (vmg_spy_prep)."""
+    hip.require_cuda(img, mean, std)
+    if img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3 or not img.is_contiguous() or mean.numel() != 3 or std.numel() != 3 or \
+            mean.dtype != torch.float32 or std.dtype != torch.float32:
+        raise HipError("spy_prep: contiguous fp32 (n,3,h,w) image and fp32 mean / std of 3 elements expected")
+    n, _, h, w = img.shape
+    out = torch.empty((n, h, w, 8), dtype=dtype, device=img.device)
+    hip.check(hip.lib().vmg_spy_prep(hip.dtype_code(dtype), img.data_ptr(), mean.contiguous().data_ptr(), std.contiguous().data_ptr(), out.data_ptr(), n, h, w, hip.stream_ptr()),
+              "vmg_spy_prep")
+    return out
+
+
 def spy_operand(ref: torch.Tensor, warped: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """[ref RGB | warped RGB | flow] (n,h,w,8) in ref's dtype from ref, warped (n,h,w,8: RGB in channels 0..2) and up (n,h,w,2) fp32 (vmg_spy_operand_fwd)."""
     hip.require_cuda(ref, warped, up)
@@ -905,6 +918,18 @@ def warp_bilinear_backward(x: torch.Tensor, flow: torch.Tensor, dy: torch.Tensor
         ACC_POOL.give(dx_acc)
         return dx, dflow
     return dx_acc.to(x.dtype), dflow
+
+
+def flow_smooth(x: torch.Tensor, r: int, backward: bool = False) -> torch.Tensor:
+    """x (..., H, W) contiguous fp32 planes: forward the r x r block mean of the reflect-padded plane spread back over the block; backward=True: x is the output
+    gradient, the result the input gradient (vmg_flow_smooth)."""
+    hip.require_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() < 2:
+        raise HipError("flow_smooth: contiguous fp32 (..., H, W) expected")
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    hip.check(hip.lib().vmg_flow_smooth(x.data_ptr(), out.data_ptr(), x.numel() // (H * W), H, W, int(r), 1 if backward else 0, hip.stream_ptr()), "vmg_flow_smooth")
+    return out
 
 
 def warp_nearest_planes(loc: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:

@@ -142,6 +142,9 @@ class SPyNet(nn.Module):
         resized = (h_up, w_up) != (h, w)
 
         def prep(img):
+            from . import kernels as K
+            if not resized and not img.requires_grad and compute_dtype in (torch.float32, torch.bfloat16):
+                return K.spy_prep(img.float().contiguous(), self.mean.float(), self.std.float(), compute_dtype)  # normalise + channels-last + 3 -> 8 channels + cast: one kernel
             img = (img.float() - self.mean) / self.std
             if resized:  # (sizes that are no multiple of 32: a plain bilinear resize, models/vmg.py:104-113)
                 img = F.interpolate(img, size=(h_up, w_up), mode="bilinear", align_corners=False)
@@ -559,13 +562,14 @@ class Mlp_encoder(nn.Module):
     @staticmethod
     def flow_smoothing(flow, r):
         """reflect-pad to a multiple of r, r x r mean, nearest x r, crop (function.py:1466-1478)."""
-        B, T, C, H, W = flow.shape
-        f = flow.reshape(-1, C, H, W)
+        H, W = flow.shape[-2:]
         hf, wf = int(np.ceil(H / r)) * r, int(np.ceil(W / r)) * r
+        if flow.is_cuda and hf - H < H and wf - W < W:
+            return FH.flow_smooth(flow, r)  # one kernel each way (csrc/warp.hip)
+        B, T, C = flow.shape[:3]
+        f = flow.reshape(-1, C, H, W)
         f = F.pad(f, (0, wf - W, 0, hf - H), mode="reflect")
         f = F.adaptive_avg_pool2d(f, (hf // r, wf // r))
-        # nearest x r (an integer factor) = every mean repeated over its r x r block: expand + reshape, whose backward is a block sum
-        # (torch's upsample_nearest2d backward kernel took 72 us per call on these small maps)
         n_, c_, hq, wq = f.shape
         f = f[:, :, :, None, :, None].expand(n_, c_, hq, r, wq, r).reshape(n_, c_, hq * r, wq * r)[..., :H, :W].contiguous()
         return f.view(B, T, C, H, W)
