@@ -964,10 +964,11 @@ def ltam_forward(q, keys, vals, loc, rpe, decay, heads, wh, ww, scale):
     return out, lse
 
 
-def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale, dk_into=None, dv_into=None):
+def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww, scale, dk_into=None, dv_into=None, drpe_into=None):
     """dq, dk[j], dv[j], drpe.  dk / dv are FP32 sums (q's shape) for every tensor dtype: the caller rounds them once.  dk_into / dv_into: per
     key-frame an existing fp32 accumulator to scatter into (the gradient of a frame that several calls attend to is summed by the kernel's
-    atomics, see functional.grad_bank), or None for a fresh zeroed one."""
+    atomics, see functional.grad_bank), or None for a fresh zeroed one.  drpe_into: an fp32 tensor of rpe's shape to ADD the table gradient into (the
+    parameter's .grad in the deferred weight-gradient mode) instead of a fresh zeroed one."""
     n, h, w, c = q.shape
     t = len(keys)
     dout = dout.contiguous()
@@ -985,7 +986,9 @@ def ltam_backward(q, keys, vals, loc, rpe, decay, out, lse, dout, heads, wh, ww,
                 dk[i] = acc[slot]
             else:
                 dv[i - t] = acc[slot]
-    drpe = torch.zeros_like(rpe)
+    if drpe_into is not None and (drpe_into.shape != rpe.shape or drpe_into.dtype != torch.float32 or not drpe_into.is_contiguous()):
+        raise HipError("ltam_backward: drpe_into must be a contiguous fp32 tensor of the table's shape")
+    drpe = drpe_into if drpe_into is not None else torch.zeros_like(rpe)
     hip.check(hip.lib().vmg_ltam_bwd(hip.dtype_code(q.dtype), q.data_ptr(), _ptrs(keys), _ptrs(vals), loc.data_ptr(), rpe.data_ptr(),
                                      decay.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), _ptrs(dk), _ptrs(dv),
                                      drpe.data_ptr(), n, h, w, c, heads, wh, ww, t, scale, hip.stream_ptr()), "vmg_ltam_bwd")
