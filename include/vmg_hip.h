@@ -175,7 +175,8 @@ void vmg_replay_destroy(void* replay);
  * vmg_conv_pack (kind 0) / vmg_convws_pack (kind 1) call.  vmg_pack_entry fills one entry in HOST memory (the caller copies the array to
  * the device once; it stays valid while the weight and pack buffers stay where they are) and returns the number of 256-thread blocks the
  * entry wants (> 0; negative: error); blk0 = sum of the block counts of the entries before it.  vmg_pack_run repacks all of them in ONE
- * launch of total_blocks blocks. */
+ * launch of total_blocks blocks; BEHIND the n entries plan_dev holds total_blocks int32: the index of the entry that owns each block (entry i owns blocks
+ * [blk0_i, blk0_i + its count)). */
 int vmg_pack_entry_bytes(void);
 int vmg_pack_entry(void* entry, int kind, int dtype, const float* w, int O, int I, int ks, int o0, int on, int nsrc, const int* src_off,
                    const int* src_ch, int transpose_flip, int cout_tiles, void* packed, int blk0);

@@ -1603,6 +1603,8 @@ struct PackK {
   char* out;
   int O, I, ks, o0, on, nsrc, transpose_flip, cob, ncb, nstages, ss_elems;  // ss_elems = stage stride in elements
   int groups;  // > 1: w is the (O, I, ks, ks) weight of a GROUPED convolution (I = channels per group); the pack is the dense block-diagonal operator
+  int fast3;   // 3x3, one group: the item form below (pack3_item) applies; `units` = its work items + padding vectors
+  long long units;
   short src_off[MAX_ISRC], src_ch[MAX_ISRC], src_st0[MAX_ISRC], src_nst[MAX_ISRC];
 };
 
@@ -1631,13 +1633,14 @@ __device__ __forceinline__ float pack_weight_value(const PackK& p, int oc, int k
 // fp32).  Round 4: the per-element form ran at 0.4 TB/s -- 372 us per launch for the full configuration's weights, 2 % of its step.
 template <typename T>
 __device__ __forceinline__ void pack_std_vec8(const PackK& p, long long i8) {
-  const long long i = i8 * 8;
+  // (32-bit index arithmetic: the host admits packs below 2^31 elements only -- a 64-bit division costs ~150 instructions, and there were four per vector)
+  const unsigned i = (unsigned)i8 * 8u;
   const int KK = p.ks * p.ks, KSTG = kstg(p.ks);
   const int body = KSTG * 4 * p.cob * 8;
-  const int within = (int)(i % p.ss_elems);
-  long long r = i / p.ss_elems;
-  const int stage = (int)(r % p.nstages);
-  const int cb = (int)(r / p.nstages);
+  const unsigned r = i / (unsigned)p.ss_elems;
+  const int within = (int)(i - r * (unsigned)p.ss_elems);
+  const int cb = (int)(r / (unsigned)p.nstages);
+  const int stage = (int)(r - (unsigned)cb * (unsigned)p.nstages);
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -1681,12 +1684,12 @@ __global__ void conv_pack_kernel(const PackK p) {
 
 // weight-streaming layout: [cout block][stage][k-step jj 0..2][lane group g][co][8] bf16, K slots by ws_slot()
 __device__ __forceinline__ void pack_ws_vec8(const PackK& p, long long i8) {  // (eight elements per call, see pack_std_vec8)
-  long long t = i8;
-  const int co = (int)(t % p.cob); t /= p.cob;
+  unsigned t = (unsigned)i8;
+  const int co = (int)(t % (unsigned)p.cob); t /= (unsigned)p.cob;
   const int g = (int)(t & 3); t >>= 2;
-  const int jj = (int)(t % 3); t /= 3;
-  const int stage = (int)(t % p.nstages);
-  const int cb = (int)(t / p.nstages);
+  const int jj = (int)(t % 3u); t /= 3u;
+  const int cb = (int)(t / (unsigned)p.nstages);
+  const int stage = (int)(t - (unsigned)cb * (unsigned)p.nstages);
   int s = 0;
   while (s + 1 < p.nsrc && stage >= p.src_st0[s + 1]) ++s;
   const int j = (stage - p.src_st0[s]) * 3 + jj;
@@ -1705,6 +1708,107 @@ __device__ __forceinline__ void pack_ws_vec8(const PackK& p, long long i8) {  //
   *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + i8 * 8) = o;
 }
 
+// ---- 3x3, one group: ONE THREAD PER (cout block, 32-channel block, chunk g, output channel co) -- an "item" = the 8 K-side channels x 9 taps of one chunk.
+// The vector form above reads a packed vector's 8 channels with a stride of 9 floats (and the lanes of a wave sit 4 KB apart): every 64-byte line of the weight is
+// touched by nine different instructions, 4 bytes at a time -- 0.9 TB/s.  An item reads its 72 floats as 18 aligned 16-byte loads (forward packs: 288 contiguous
+// bytes; data-gradient packs: eight 36-byte tap rows, adjacent lanes adjacent rows) and writes nine 16-byte vectors, adjacent lanes adjacent vectors.
+__device__ __forceinline__ int pack3_blocks(const PackK& p, int s) { return ((p.src_ch[s] >> 3) + 3) >> 2; }
+
+template <typename T, bool WS>
+__device__ __forceinline__ void pack3_store(const PackK& p, long long elem, const float (&v)[8]) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + elem) = o;
+  } else {
+    f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + elem);
+    o[0] = f32x4{v[0], v[1], v[2], v[3]};
+    o[1] = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+
+template <typename T, bool WS>
+__device__ __forceinline__ void pack3_item(const PackK& p, long long item, long long items) {
+  const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (item >= items) {  // (standard layout only) the zero padding between a stage's body and its 4-KiB-aligned stride
+    const int body8 = 3 * 4 * p.cob, pad8 = p.ss_elems / 8 - body8;
+    const unsigned r = (unsigned)(item - items);
+    const unsigned stage = r / (unsigned)pad8;
+    pack3_store<T, WS>(p, (long long)stage * p.ss_elems + (long long)(body8 + (int)(r - stage * (unsigned)pad8)) * 8, zero8);
+    return;
+  }
+  unsigned t = (unsigned)item / (unsigned)p.cob;  // (32-bit index arithmetic, see pack_std_vec8)
+  const int co = (int)((unsigned)item - t * (unsigned)p.cob);
+  const int g = (int)(t & 3);
+  t >>= 2;
+  int nblk = 0;
+  for (int s = 0; s < p.nsrc; ++s) nblk += pack3_blocks(p, s);
+  const int cb = (int)(t / (unsigned)nblk), blk = (int)(t - (unsigned)cb * (unsigned)nblk);
+  int s = 0, b0 = 0;
+  while (s + 1 < p.nsrc && blk >= b0 + pack3_blocks(p, s)) { b0 += pack3_blocks(p, s); ++s; }
+  const int cbk = blk - b0, CH = p.src_ch[s] >> 3, nfull = CH >> 2;
+  const bool rem = WS && cbk == nfull;  // the weight-streaming layout's remainder block (CH % 4 == 2: two chunks, two taps per k-step)
+  if (rem && g >= 2) return;
+  const int q = 4 * cbk + g, col = cb * p.cob + co;
+  const bool valid = q < CH && col < p.on;
+  float v[9][8];  // [tap][channel of the chunk]
+  if (valid) {
+    const int kc = p.src_off[s] + q * 8, oc = p.o0 + col;
+    if (!p.transpose_flip) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.w + ((long long)oc * p.I + kc) * 9);  // 72 contiguous floats, 16-byte aligned (kc, I multiples of 8; the host checks w)
+      float buf[72];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        const f32x4 x = src[i];
+        buf[4 * i] = x[0]; buf[4 * i + 1] = x[1]; buf[4 * i + 2] = x[2]; buf[4 * i + 3] = x[3];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) v[tap][e] = buf[e * 9 + tap];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* src = p.w + ((long long)(kc + e) * p.I + oc) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) v[tap][e] = src[8 - tap];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[tap][e] = 0.f;
+  }
+  const int st0 = p.src_st0[s];
+  if (!WS) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      pack3_store<T, WS>(p, ((long long)cb * p.nstages + st0 + cbk * 3 + ky) * p.ss_elems + (long long)((kx * 4 + g) * p.cob + co) * 8, v[tap]);
+    }
+  } else {
+    auto slot = [&](int j, int gg) { return ((((long long)cb * p.nstages + st0 + j / 3) * 3 + j % 3) * 4 + gg) * p.cob * 8 + (long long)co * 8; };
+    if (!rem) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) pack3_store<T, WS>(p, slot(cbk * 9 + tap, g), v[tap]);
+    } else {  // chunk 4 nfull + g (g = 0, 1): k-step 9 nfull + tap / 2, lane group g | (tap & 1) << 1; the empty slots of its column are zero
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) pack3_store<T, WS>(p, slot(9 * nfull + (tap >> 1), g | ((tap & 1) << 1)), v[tap]);
+      pack3_store<T, WS>(p, slot(9 * nfull + 4, g | 2), zero8);
+      pack3_store<T, WS>(p, slot(9 * nfull + 5, g), zero8);
+      pack3_store<T, WS>(p, slot(9 * nfull + 5, g | 2), zero8);
+    }
+  }
+}
+
+template <typename T, bool WS>
+__global__ void pack3_kernel(const PackK p) {
+  const long long items = (long long)p.units - (WS ? 0 : (long long)p.ncb * p.nstages * (p.ss_elems / 8 - 3 * 4 * p.cob));
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < p.units; i += (long long)gridDim.x * blockDim.x) pack3_item<T, WS>(p, i, items);
+}
+
 __global__ void convws_pack_kernel(const PackK p) {
   const long long total8 = (long long)p.ncb * p.nstages * 3 * 4 * p.cob;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) pack_ws_vec8(p, i);
@@ -1721,16 +1825,9 @@ struct PackEntry {
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __restrict__ plan, int n) {
   __shared__ PackEntry ent;
-  __shared__ int which;
-  if (threadIdx.x == 0) {  // the entry whose block range holds blockIdx.x
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (plan[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    which = lo;
-  }
-  __syncthreads();
+  // the entry that owns this block: a table of one int per block behind the n entries (round 4: a binary search over the entries' block ranges was ten DEPENDENT
+  // global loads by one thread, ~10 us before the block's first useful instruction)
+  const int which = reinterpret_cast<const int*>(plan + n)[blockIdx.x];
   {
     const int* src = reinterpret_cast<const int*>(plan + which);
     int* dst = reinterpret_cast<int*>(&ent);
@@ -1739,6 +1836,13 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
   __syncthreads();
   const long long stride = (long long)ent.nblk * 256, total8 = ent.total / 8;  // (every layout is made of whole 8-element vectors)
   long long i = (long long)((int)blockIdx.x - ent.blk0) * 256 + threadIdx.x;
+  if (ent.p.fast3) {
+    const long long units = ent.p.units, items = units - (ent.kind == 1 ? 0 : (long long)ent.p.ncb * ent.p.nstages * (ent.p.ss_elems / 8 - 3 * 4 * ent.p.cob));
+    if (ent.kind == 1) { for (; i < units; i += stride) pack3_item<bf16, true>(ent.p, i, items); }
+    else if (ent.dtype == VMG_BF16) { for (; i < units; i += stride) pack3_item<bf16, false>(ent.p, i, items); }
+    else { for (; i < units; i += stride) pack3_item<float, false>(ent.p, i, items); }
+    return;
+  }
   if (ent.kind == 1) { for (; i < total8; i += stride) pack_ws_vec8(ent.p, i); }
   else if (ent.dtype == VMG_BF16) { for (; i < total8; i += stride) pack_std_vec8<bf16>(ent.p, i); }
   else { for (; i < total8; i += stride) pack_std_vec8<float>(ent.p, i); }
@@ -2011,6 +2115,13 @@ static int fill_pack_std(PackK& p, long long& total, int dtype, const float* w, 
   const int es = dtype == VMG_BF16 ? 2 : 4;
   p.ss_elems = stage_stride(ks, cout_tiles, es * 8) / es;
   total = (long long)p.ncb * p.nstages * p.ss_elems;
+  VMG_CHECK(total < (1ll << 31), "conv_pack: pack of %lld elements (the index arithmetic is 32-bit)", total);
+  if (ks == 3 && groups == 1 && (transpose_flip || (uintptr_t)w % 16 == 0) && (transpose_flip || I % 4 == 0)) {  // the item form (pack3_item)
+    int nblk = 0;
+    for (int s = 0; s < n; ++s) nblk += ((p.src_ch[s] >> 3) + 3) >> 2;
+    p.fast3 = 1;
+    p.units = (long long)p.ncb * nblk * 4 * p.cob + (long long)p.ncb * p.nstages * (p.ss_elems / 8 - 3 * 4 * p.cob);
+  }
   return 0;
 }
 
@@ -2020,6 +2131,13 @@ extern "C" int vmg_conv_pack(int dtype, const float* w, int O, int I, int ks, in
   long long total = 0;
   const int rc = fill_pack_std(p, total, dtype, w, O, I, ks, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
   if (rc) return rc;
+  if (p.fast3) {
+    const int fb = (int)((p.units + 255) / 256 > 4096 ? 4096 : (p.units + 255) / 256);
+    if (dtype == VMG_BF16) hipLaunchKernelGGL((pack3_kernel<bf16, false>), dim3(fb), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((pack3_kernel<float, false>), dim3(fb), dim3(256), 0, (hipStream_t)stream, p);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == VMG_BF16) hipLaunchKernelGGL(conv_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -2067,6 +2185,15 @@ static int fill_pack_ws(PackK& p, long long& total, const float* w, int O, int I
   p.w = w; p.out = (char*)packed; p.O = O; p.I = I; p.ks = 3; p.o0 = o0; p.on = on; p.transpose_flip = transpose_flip; p.groups = groups;
   p.cob = cout_tiles * 16; p.ncb = cdiv(on, p.cob);
   total = (long long)p.ncb * p.nstages * 3 * 4 * p.cob * 8;
+  VMG_CHECK(total < (1ll << 31), "convws_pack: pack of %lld elements (the index arithmetic is 32-bit)", total);
+  bool rem_ok = true;  // the item form knows the remainder blocks of 0 or 2 chunks (all the conv kernel admits)
+  for (int s = 0; s < p.nsrc; ++s) rem_ok = rem_ok && (((p.src_ch[s] >> 3) & 3) == 0 || ((p.src_ch[s] >> 3) & 3) == 2);
+  if (groups == 1 && rem_ok && (transpose_flip || ((uintptr_t)w % 16 == 0 && I % 4 == 0))) {
+    int nblk = 0;
+    for (int s = 0; s < p.nsrc; ++s) nblk += ((p.src_ch[s] >> 3) + 3) >> 2;
+    p.fast3 = 1;
+    p.units = (long long)p.ncb * nblk * 4 * p.cob;
+  }
   return 0;
 }
 
@@ -2076,6 +2203,12 @@ extern "C" int vmg_convws_pack(const float* w, int O, int I, int o0, int on, int
   long long total = 0;
   const int rc = fill_pack_ws(p, total, w, O, I, o0, on, nsrc, src_off, src_ch, transpose_flip, cout_tiles, packed);
   if (rc) return rc;
+  if (p.fast3) {
+    const int fb = (int)((p.units + 255) / 256 > 4096 ? 4096 : (p.units + 255) / 256);
+    hipLaunchKernelGGL((pack3_kernel<bf16, true>), dim3(fb), dim3(256), 0, (hipStream_t)stream, p);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(convws_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   VMG_LAUNCH_CHECK();
@@ -2098,7 +2231,7 @@ extern "C" int vmg_pack_entry(void* entry, int kind, int dtype, const float* w, 
   }
   if (rc) return rc;
   e.kind = kind; e.dtype = dtype; e.blk0 = blk0;
-  long long nb = (e.total + 256LL * 16 - 1) / (256LL * 16);  // ~16 elements per thread
+  long long nb = e.p.fast3 ? (e.p.units + 255) / 256 : (e.total + 256LL * 16 - 1) / (256LL * 16);  // an item (72 elements) / ~16 elements per thread
   e.nblk = (int)(nb < 1 ? 1 : (nb > 64 ? 64 : nb));
   memcpy(entry, &e, sizeof(e));
   return e.nblk;
@@ -2106,6 +2239,7 @@ extern "C" int vmg_pack_entry(void* entry, int kind, int dtype, const float* w, 
 
 extern "C" int vmg_pack_run(const void* plan_dev, int n, int total_blocks, void* stream) {
   VMG_CHECK(plan_dev && n > 0 && total_blocks > 0, "pack_run: bad arguments");
+  static_assert(sizeof(PackEntry) % 4 == 0, "the block-owner table sits behind the entries");
   hipLaunchKernelGGL(pack_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)plan_dev, n);
   VMG_LAUNCH_CHECK();
   return 0;

@@ -1135,6 +1135,7 @@ class PackPlan:
             host = (ctypes.c_char * (esz * len(packs)))()
             base = ctypes.addressof(host)
             blk = 0
+            owner = []  # entry index of every block: the kernel's blocks look their entry up here (appended to the entry array)
             for i, p in enumerate(packs):
                 wptr, O, I, o0, on, soff, sch, tf = p.call
                 nb = l.vmg_pack_entry(base + i * esz, 1 if p.layout == "ws" else 0, hip.dtype_code(p.dtype), wptr, O, I, p.ks, o0, on, len(sch),
@@ -1142,9 +1143,11 @@ class PackPlan:
                 if nb <= 0:
                     hip.check(nb if nb < 0 else -1, "vmg_pack_entry")
                 blk += nb
+                owner.extend([i] * nb)
             if self.dev is not None:
                 self.retired.append(self.dev)
-            self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(packs[0].buf.device)
+            table = struct.pack("<%di" % len(owner), *owner)
+            self.dev = torch.frombuffer(bytearray(bytes(host) + table), dtype=torch.uint8).to(packs[0].buf.device)
             self.sig, self.n, self.blocks = sig, len(packs), blk
         hip.check(l.vmg_pack_run(self.dev.data_ptr(), self.n, self.blocks, hip.stream_ptr()), "vmg_pack_run")
 
