@@ -771,3 +771,47 @@ def test_grouped_conv_dense_route_matches_grouped_launches(geom):
     br = R.seeded((Oc,), 1502, 0.1)
     want = F.gelu(F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=G)).permute(0, 2, 3, 1)
     assert float((res[1][0].cpu() - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["relu3x3", "gelu1x1", "relu7x7", "lrelu3x3"])
+def test_activation_derivative_fused_into_the_consumers_data_gradient(dtype, case):
+    """conv2d(..., fuse_src_act=True) (round 4, functional._ActTok): conv -> activation -> conv where the second convolution's data-gradient launch applies the
+    first one's activation derivative in its epilogue and the first backward skips its own pass (RCAB's ReLU, the MLP's GELU, SPyNet's 7x7 ReLU chain).  Same
+    outputs; every gradient equals the unfused path -- bit-exact for ReLU (a 0 / 1 mask), within a rounding for leaky ReLU / GELU in bf16 -- and act_backward is not
+    called on the fused path."""
+    from vmg_amd import functional as FH, hip, kernels as K
+    ks, act, slope = {"relu3x3": (3, hip.ACT_RELU, 0.0), "gelu1x1": (1, hip.ACT_GELU, 0.0), "relu7x7": (7, hip.ACT_RELU, 0.0), "lrelu3x3": (3, hip.ACT_LRELU, 0.1)}[case]
+    N, H, W, C0, C1, C2 = 2, 12, 10, 16, 32, 16
+    g = torch.Generator(device="cuda").manual_seed(61)
+    x0 = torch.randn((N, H, W, C0), generator=g, device="cuda").to(dtype)
+    w1 = (torch.randn((C1, C0, ks, ks), generator=g, device="cuda") * (C0 * ks * ks) ** -0.5)
+    b1 = torch.randn(C1, generator=g, device="cuda") * 0.1
+    w2 = (torch.randn((C2, C1, ks, ks), generator=g, device="cuda") * (C1 * ks * ks) ** -0.5)
+    b2 = torch.randn(C2, generator=g, device="cuda") * 0.1
+    go = torch.randn((N, H, W, C2), generator=g, device="cuda").to(dtype)
+
+    def run(fuse):
+        x = x0.clone().requires_grad_(True)
+        ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        calls = []
+        orig = K.act_backward
+        K.act_backward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            y = FH.conv2d([x], ps[0], ps[1], N, H, W, ks=ks, act=act, slope=slope)
+            z = FH.conv2d([y], ps[2], ps[3], N, H, W, ks=ks, fuse_src_act=fuse)
+            z.backward(go)
+        finally:
+            K.act_backward = orig
+        return z.detach(), [x.grad] + [p.grad for p in ps], len(calls)
+
+    z0, g0, n0 = run(False)
+    z1, g1, n1 = run(True)
+    assert n0 == 1 and n1 == 0
+    assert torch.equal(z0, z1)
+    for k, (a, b) in enumerate(zip(g0, g1)):
+        if act == hip.ACT_RELU and (k == 0 or dtype == torch.bfloat16):  # (the fp32 weight gradients are float atomics: run-to-run differences of an ulp)
+            assert torch.equal(a, b)
+        else:
+            tol = 1e-5 if dtype == torch.float32 else 2e-2
+            assert float((a.float() - b.float()).abs().max()) <= tol * max(1.0, float(a.float().abs().max()))

@@ -531,12 +531,29 @@ def _act_grad(dy: torch.Tensor, y: Optional[torch.Tensor], pre: Optional[torch.T
     return K.act_backward(dy, pre if act == hip.ACT_GELU else y, act, slope, alpha)
 
 
+class _ActTok:
+    """What a convolution with a fused activation tells its ONLY consumer, when that consumer is a convolution too (conv2d(..., fuse_src_act=True)): the
+    consumer's data-gradient launch multiplies by the activation's derivative in its epilogue (the `aux` / `actgrad` operands the residual chains use) and sets
+    `masked`; the producer's backward then takes the gradient it receives as the pre-activation gradient and skips its own derivative pass (vmg_act_bwd: one full
+    read-modify-write of the tensor per convolution -- 66 launches per train step before round 4).  ReLU: the same bits (the mask is 0 / 1); leaky ReLU and GELU:
+    one rounding instead of two."""
+    __slots__ = ("act", "slope", "alpha", "pre", "masked")
+
+    def __init__(self, act, slope, alpha):
+        self.act, self.slope, self.alpha, self.pre, self.masked = act, slope, alpha, None, False
+
+
+_ACTGRAD_CODE = {hip.ACT_RELU: 1, hip.ACT_LRELU: 2, hip.ACT_GELU: 3}
+
+
 class _Conv2d(_Fn):
     """out = [res +] alpha * act(conv(cat(srcs)) + bias), optional PixelShuffle(2) store."""
 
     @staticmethod
     def forward(ctx, weight, bias, res, cfg, *srcs):
-        ks, act, slope, alpha, pixel_shuffle, N, H, W = cfg
+        ks, act, slope, alpha, pixel_shuffle, N, H, W, tok, src_tok = cfg
+        cfg = cfg[:8]
+        ctx.tok, ctx.src_tok = tok, src_tok
         dt = srcs[0].dtype
         src_ch = [s.shape[-1] for s in srcs]
         srcs_p = [_pad_channels(s) for s in srcs]
@@ -554,6 +571,8 @@ class _Conv2d(_Fn):
                                   pixel_shuffle=pixel_shuffle and not ps_after, want_pre=need_pre, mt=mt, deep=deep)
         if ps_after:
             out = K.pixel_shuffle(out, N, H, W)
+        if tok is not None:
+            tok.pre = pre  # (GELU: the consumer's epilogue needs the pre-activation)
         ctx.cfg = cfg
         ctx.src_ch = src_ch
         ctx.src_shapes = [tuple(t.shape) for t in srcs]
@@ -579,7 +598,10 @@ class _Conv2d(_Fn):
         srcs_p = ctx.saved_tensors[3:]
         dy = dy.contiguous()
         d_res = dy.reshape(ctx.res_shape) if ctx.has_res else None
-        if pixel_shuffle and act != hip.ACT_GELU and dy.shape[-1] % (8 if dy.dtype == torch.bfloat16 else 4) == 0:
+        if ctx.tok is not None and ctx.tok.masked:
+            ctx.tok.masked = False
+            dpre = dy  # the consumer's data-gradient launch applied the derivative (see _ActTok)
+        elif pixel_shuffle and act != hip.ACT_GELU and dy.shape[-1] % (8 if dy.dtype == torch.bfloat16 else 4) == 0:
             # depth-to-space undone on the gradient and the activation derivative taken from the HR output in one pass
             dpre = K.pixel_unshuffle_actgrad(dy, y if act != hip.ACT_NONE else None, N, H, W, act, slope, alpha)
         else:
@@ -597,7 +619,14 @@ class _Conv2d(_Fn):
             if ctx.needs_input_grad[4 + i]:
                 tiles, mt, deep = choose_tiling(N * H * W, c, ks, dpre.dtype, [weight.shape[0]])
                 pw = packed(weight, dpre.dtype, "dgrad", None, off, c, tiles=tiles, deep=deep)
-                dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep)
+                st = ctx.src_tok
+                if st is not None:  # the source is a convolution's activated output and this is its only consumer: its derivative in this launch's epilogue
+                    ref = st.pre if st.act == hip.ACT_GELU else srcs_p[i]
+                    dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep, aux=ref.reshape(N, H, W, c), actgrad=_ACTGRAD_CODE[st.act],
+                                           slope=st.slope, alpha=st.alpha)
+                    st.masked = True
+                else:
+                    dx, _ = K.conv_forward([dpre_p], pw, None, N, H, W, mt=mt, deep=deep)
                 d_srcs.append(dx.reshape(ctx.src_shapes[i]))
             else:
                 d_srcs.append(None)
@@ -617,10 +646,21 @@ class _Conv2d(_Fn):
 
 def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int,
            ks: int = 3, act: int = hip.ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
-           pixel_shuffle: bool = False) -> torch.Tensor:
-    """Channels-last convolution / linear over N*H*W pixels; srcs are virtually concatenated along channels."""
-    cfg = (ks, act, float(slope), float(alpha), bool(pixel_shuffle), int(N), int(H), int(W))
-    return _Conv2d.apply(weight, bias, res, cfg, *srcs)
+           pixel_shuffle: bool = False, fuse_src_act: bool = False) -> torch.Tensor:
+    """Channels-last convolution / linear over N*H*W pixels; srcs are virtually concatenated along channels.
+    fuse_src_act: the caller's promise that the (single) source is the activated output of another conv2d call and has NO other consumer -- the activation's
+    derivative is then applied by this convolution's data-gradient launch (see _ActTok)."""
+    grad = torch.is_grad_enabled()
+    tok = src_tok = None
+    if grad and act != hip.ACT_NONE and res is None and not pixel_shuffle:
+        tok = _ActTok(act, float(slope), float(alpha))
+    if grad and fuse_src_act and len(srcs) == 1 and srcs[0].requires_grad and srcs[0].shape[-1] % 8 == 0:
+        src_tok = getattr(srcs[0], "_vmg_act_tok", None)
+    cfg = (ks, act, float(slope), float(alpha), bool(pixel_shuffle), int(N), int(H), int(W), tok, src_tok)
+    out = _Conv2d.apply(weight, bias, res, cfg, *srcs)
+    if tok is not None:
+        out._vmg_act_tok = tok
+    return out
 
 
 class _GroupedConv2d(_Fn):
@@ -919,12 +959,16 @@ def residual_chain(srcs: Sequence[torch.Tensor], conv0, blocks, r_scaling: float
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = hip.ACT_NONE, alpha: float = 1.0,
-           res: Optional[torch.Tensor] = None, slope: float = 0.0) -> torch.Tensor:
+           res: Optional[torch.Tensor] = None, slope: float = 0.0, fuse_src_act: bool = False) -> torch.Tensor:
     """y[..., O] = act(x[..., I] @ W^T + b) * alpha (+ res): the KS = 1 convolution on (M, C) rows."""
     M = x.numel() // x.shape[-1]
     out = conv2d([x], weight, bias, 1, 1, M, ks=1, act=act, slope=slope, alpha=alpha,
-                 res=None if res is None else res)
-    return out.reshape(*x.shape[:-1], weight.shape[0])
+                 res=None if res is None else res, fuse_src_act=fuse_src_act)
+    y = out.reshape(*x.shape[:-1], weight.shape[0])
+    tok = getattr(out, "_vmg_act_tok", None)
+    if tok is not None and y is not out:
+        y._vmg_act_tok = tok  # (the reshape is a view of the same values: the consumer may still fuse the derivative)
+    return y
 
 
 class _LayerNorm(_Fn):

@@ -82,7 +82,7 @@ class SPyNetBasicModule(nn.Module):
                 y = [y[0].to(inner_dtype)]
             if inner_dtype is not None and i == last:
                 y = [y[0].to(srcs[0].dtype)]
-            y = [FH.conv2d(y, m.conv.weight, m.conv.bias, n, h, w, ks=7, act=ACT_RELU if m.act else hip.ACT_NONE)]
+            y = [FH.conv2d(y, m.conv.weight, m.conv.bias, n, h, w, ks=7, act=ACT_RELU if m.act else hip.ACT_NONE, fuse_src_act=i > 0)]
         return y[0]
 
 
@@ -181,7 +181,7 @@ class RCAB(nn.Module):
         B, T, H, W, C = x.shape
         N = B * T
         r = conv(self.body[0], [x], N, H, W, act=ACT_RELU)
-        r = conv(self.body[2], [r], N, H, W)
+        r = conv(self.body[2], [r], N, H, W, fuse_src_act=True)  # (the ReLU's derivative rides on this conv's data-gradient launch)
         du = self.body[3].conv_du
         return FH.channel_attention_residual(r, (x if x_res is None else x_res).reshape(N, H, W, C), du[0].weight, du[0].bias, du[2].weight, du[2].bias,
                                              out_scale).reshape(B, T, H, W, C)
@@ -196,7 +196,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
     def forward(self, x):
-        return lin(self.fc2, lin(self.fc1, x, act=ACT_GELU))
+        return lin(self.fc2, lin(self.fc1, x, act=ACT_GELU), fuse_src_act=True)
 
 
 class Mlp_cnn(nn.Module):
@@ -216,7 +216,7 @@ class Mlp_cnn(nn.Module):
             h = conv(self.fc1, [x], N, H, W, act=ACT_GELU)
         else:
             h = FH.grouped_conv2d(x, self.fc1.weight, self.fc1.bias, self.n_groups, N, H, W, ks=3, act=ACT_GELU)
-        return lin(self.fc2, h, res=res).reshape(B, T, H, W, C)
+        return lin(self.fc2, h, res=res, fuse_src_act=True).reshape(B, T, H, W, C)
 
 
 class Enhanced_MorphFCs_decay(nn.Module):
