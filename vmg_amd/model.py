@@ -775,7 +775,7 @@ class VMG(nn.Module):
         o = conv(self.upconv1, [y], N, H, W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
         o = conv(self.upconv2, [o], N, 2 * H, 2 * W, act=ACT_LRELU, slope=0.1, pixel_shuffle=True)
         o = conv(self.HRconv, [o], N, 4 * H, 4 * W, act=ACT_LRELU, slope=0.1)
-        return conv(self.conv_last, [o], N, 4 * H, 4 * W)
+        return conv(self.conv_last, [o], N, 4 * H, 4 * W, fuse_src_act=True)  # (HRconv's leaky-ReLU derivative in conv_last's data-gradient epilogue: one HR-size pass less)
 
     def forward(self, x, flow_pretrained=None, config_amp=None):
         B, D, C, H, W = x.size()
