@@ -394,11 +394,9 @@ class _AccPool:
         return lst.pop() if lst else torch.zeros(tuple(shape), dtype=torch.float32, device=device)
 
     def give(self, buf: torch.Tensor) -> None:
-        if len(self.free) > 32:  # (many distinct shapes -- e.g. a sweep over crop sizes: do not hoard buffers of shapes that may never come back)
-            self.free.clear()
-        lst = self.free.setdefault((tuple(buf.shape), str(buf.device)), [])
-        if len(lst) < 16:
-            lst.append(buf)
+        # (never dropped on its own: a captured hipGraph has the addresses of the buffers it used baked into its kernel nodes -- the same reason
+        #  PackPlan retires its tables instead of freeing them; clear() is the caller's explicit decision)
+        self.free.setdefault((tuple(buf.shape), str(buf.device)), []).append(buf)
 
     def clear(self) -> None:
         self.free.clear()
