@@ -304,6 +304,92 @@ __global__ __launch_bounds__(256) void morph_scatter_kernel(const T* __restrict_
   }
 }
 
+// ---- the same two maps through an LDS tile, ONE WORKGROUP PER GROUP (chunk pixels of a line x all channels).  The element-wise kernels above read x with runs of S
+// elements (S = Cp / chunk: 2 or 3 at 256 x 448, where the chunks are 64 / 112 pixels long) and pay six 64-bit divisions per element: 1.2 TB/s, 36 ms of the 319 ms
+// Vimeo-size step.  Here the pixel rows come in as whole 16-byte vectors (a pixel's channels are contiguous), the permutation f = p * S + s <-> channel k * S + s
+// happens between LDS and registers, and the token rows leave as 16-byte vectors; the 64-bit arithmetic is per group.
+template <typename T>
+__device__ __forceinline__ void tok_group_origin(const TokGeo& g, long long group, int& gi, long long& base, long long& step) {
+  gi = (int)(group % g.gpl);
+  const long long r = group / g.gpl;
+  const int lines = g.axis == 0 ? g.W : g.H;
+  const int line = (int)(r % lines);
+  const long long bt = r / lines;
+  // element offset of position `pos` of the line: base + pos * step
+  base = g.axis == 0 ? (bt * g.H * g.W + line) * (long long)g.C : ((bt * g.H + line) * (long long)g.W) * g.C;
+  step = g.axis == 0 ? (long long)g.W * g.C : (long long)g.C;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void morph_gather_lds_kernel(const T* __restrict__ x, T* __restrict__ tok, const TokGeo g) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+  T* tile = reinterpret_cast<T*>(tile_raw);  // [chunk][ld] (row stride ld: a multiple of the vector): channels >= C and positions past the line are zero
+  const int extent = g.axis == 0 ? g.H : g.W;
+  const int cvec = g.C / VN, lvec = g.ld / VN;  // (the host admits C a multiple of VN here; ld is one by construction)
+  for (long long group = blockIdx.x; group < g.ngroups; group += gridDim.x) {
+    int gi;
+    long long base, step;
+    tok_group_origin<T>(g, group, gi, base, step);
+    for (int i = threadIdx.x; i < g.chunk * lvec; i += 256) {
+      const int p = i / lvec, v = i - p * lvec;
+      const int pos = gi * g.chunk + p;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      if (v < cvec && pos < extent) val = *reinterpret_cast<const u32x4*>(x + base + pos * step + v * VN);
+      *reinterpret_cast<u32x4*>(tile + p * g.ld + v * VN) = val;
+    }
+    __syncthreads();
+    T* rows = tok + group * g.chunk * (long long)g.ld;
+    for (int i = threadIdx.x; i < g.chunk * lvec; i += 256) {
+      const int k = i / lvec, v = i - k * lvec;
+      int f = v * VN, p = f / g.S, sc = f - p * g.S;
+      alignas(16) T o[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        o[e] = f < g.Cp ? tile[p * g.ld + k * g.S + sc] : from_f32<T>(0.f);
+        ++f;
+        if (++sc == g.S) { sc = 0; ++p; }
+      }
+      *reinterpret_cast<u32x4*>(rows + (long long)k * g.ld + v * VN) = *reinterpret_cast<const u32x4*>(o);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void morph_scatter_lds_kernel(const T* __restrict__ tok, T* __restrict__ out, const TokGeo g) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  extern __shared__ __attribute__((aligned(16))) char tile_raw[];
+  T* tile = reinterpret_cast<T*>(tile_raw);  // [chunk rows k][ld]
+  const int extent = g.axis == 0 ? g.H : g.W;
+  const int cvec = g.C / VN, lvec = g.ld / VN;
+  for (long long group = blockIdx.x; group < g.ngroups; group += gridDim.x) {
+    int gi;
+    long long base, step;
+    tok_group_origin<T>(g, group, gi, base, step);
+    const T* rows = tok + group * g.chunk * (long long)g.ld;
+    for (int i = threadIdx.x; i < g.chunk * lvec; i += 256)
+      *reinterpret_cast<u32x4*>(tile + i * VN) = *reinterpret_cast<const u32x4*>(rows + (long long)i * VN);  // (the group's rows are contiguous)
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.chunk * cvec; i += 256) {
+      const int p = i / cvec, v = i - p * cvec;
+      const int pos = gi * g.chunk + p;
+      if (pos >= extent) continue;
+      int c = v * VN, k = c / g.S, sc = c - k * g.S;
+      alignas(16) T o[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        o[e] = tile[k * g.ld + p * g.S + sc];
+        if (++sc == g.S) { sc = 0; ++k; }
+      }
+      *reinterpret_cast<u32x4*>(out + base + pos * step + v * VN) = *reinterpret_cast<const u32x4*>(o);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 static int tok_geo(TokGeo& g, int axis, int chunk, int BT, int H, int W, int C, int Cp, int ld) {
@@ -325,6 +411,15 @@ extern "C" int vmg_morph_tokens_gather(int dtype, int axis, int chunk, const voi
   VMG_CHECK(x && tok, "morph_tokens_gather: null pointer");
   TokGeo g;
   if (int rc = tok_geo(g, axis, chunk, BT, H, W, C, Cp, ld)) return rc;
+  const int es = dtype == VMG_BF16 ? 2 : 4, vn = 16 / es;
+  const long long lds = (long long)chunk * ld * es;
+  if (C % vn == 0 && ld % vn == 0 && lds <= 64 * 1024 && ((uintptr_t)x | (uintptr_t)tok) % 16 == 0) {  // the LDS-tiled form (one workgroup per group)
+    const int gb = (int)(g.ngroups > 16384 ? 16384 : g.ngroups);
+    if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_gather_lds_kernel<bf16>, dim3(gb), dim3(256), (size_t)lds, (hipStream_t)stream, (const bf16*)x, (bf16*)tok, g);
+    else hipLaunchKernelGGL(morph_gather_lds_kernel<float>, dim3(gb), dim3(256), (size_t)lds, (hipStream_t)stream, (const float*)x, (float*)tok, g);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
   const long long total = g.ngroups * chunk * ld;
   const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
   if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_gather_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)tok, g);
@@ -338,6 +433,15 @@ extern "C" int vmg_morph_tokens_scatter(int dtype, int axis, int chunk, const vo
   VMG_CHECK(tok && out, "morph_tokens_scatter: null pointer");
   TokGeo g;
   if (int rc = tok_geo(g, axis, chunk, BT, H, W, C, Cp, ld)) return rc;
+  const int es = dtype == VMG_BF16 ? 2 : 4, vn = 16 / es;
+  const long long lds = (long long)chunk * ld * es;
+  if (C % vn == 0 && ld % vn == 0 && lds <= 64 * 1024 && ((uintptr_t)out | (uintptr_t)tok) % 16 == 0) {  // the LDS-tiled form (one workgroup per group)
+    const int gb = (int)(g.ngroups > 16384 ? 16384 : g.ngroups);
+    if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_scatter_lds_kernel<bf16>, dim3(gb), dim3(256), (size_t)lds, (hipStream_t)stream, (const bf16*)tok, (bf16*)out, g);
+    else hipLaunchKernelGGL(morph_scatter_lds_kernel<float>, dim3(gb), dim3(256), (size_t)lds, (hipStream_t)stream, (const float*)tok, (float*)out, g);
+    VMG_LAUNCH_CHECK();
+    return 0;
+  }
   const long long total = (long long)BT * H * W * C;
   const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
   if (dtype == VMG_BF16) hipLaunchKernelGGL(morph_scatter_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)tok, (bf16*)out, g);
