@@ -1,0 +1,21 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from vmg_amd import functional as FH, hip, kernels as K
+M = 802816
+for cin, cout in ((224, 224), (192, 192), (144, 144), (224, 144)):
+    x = torch.randn(M, cin, device="cuda").to(torch.bfloat16)
+    w = torch.randn(cout, cin, device="cuda") * cin ** -0.5
+    b = torch.randn(cout, device="cuda")
+    print(cin, cout, "choose_tiling:", FH.choose_tiling(M, cout, 1, torch.bfloat16, [cin]))
+    for tiles, deep in ((None, 0), FH.choose_tiling(M, cout, 1, torch.bfloat16, [cin])[::2]):
+        pw = FH.packed(w, torch.bfloat16, "fwd", [cin], tiles=tiles, deep=deep)
+        for _ in range(3):
+            K.conv_forward([x], pw, b, 1, 1, M, act=hip.ACT_RELU, deep=deep)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            K.conv_forward([x], pw, b, 1, 1, M, act=hip.ACT_RELU, deep=deep)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        print(f"   tiles {tiles} deep {deep}: {us:7.1f} us  {(M * (cin + cout) * 2) / us / 1e6:6.2f} TB/s")
